@@ -1,0 +1,196 @@
+/*
+ * pcp.h — C ABI of libpcp_hip.so: the MI355X (gfx950) implementation of the DP3
+ * point-cloud preprocessing hot path of darshil0805/Point-Cloud-Processing.
+ *
+ * The reference has no FFI of its own: its boundary is a handful of Python
+ * functions.  Every entry point below names the reference
+ * function (file:line under data_processing_pipeline/) whose arithmetic it
+ * replaces.  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer owned by the caller (e.g. a torch
+ *     ROCm tensor's data_ptr()), contiguous, of the stated dtype.  `pcp_params`
+ *     is a HOST struct read during the call.
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  Calls are asynchronous; nothing here synchronises the
+ *     device, allocates device memory or frees caller memory.
+ *   - Scratch comes from a caller-provided workspace sized by the matching
+ *     *_workspace_bytes query.  Workspaces must be 256-byte aligned.
+ *   - Return value: 0 = PCP_OK, negative = pcp_status.  No exception or abort
+ *     crosses the ABI.  pcp_strerror() gives a static message.
+ *   - No global mutable state: calls on different streams / workspaces are
+ *     independent and thread-safe.
+ */
+#ifndef PCP_H
+#define PCP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PCP_OK = 0,
+    PCP_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, bad enum value      */
+    PCP_ERR_WORKSPACE = -2,     /* workspace NULL / too small / misaligned           */
+    PCP_ERR_CAPACITY = -3,      /* caller-declared capacity cannot hold the result   */
+    PCP_ERR_LAUNCH = -4,        /* HIP reported an error launching a kernel          */
+    PCP_ERR_NO_DEVICE = -5,     /* no gfx950 device visible                          */
+    PCP_ERR_EMPTY = -6          /* a frame has zero points where >=1 is required     */
+} pcp_status;
+
+/* Pinhole intrinsics, the dict built at extract_point_clouds_one_cam.py:53-54. */
+typedef struct { double fx, fy, cx, cy; } pcp_intr;
+
+/*
+ * Every constant of the per-frame path in one place.
+ * pcp_default_params() fills in the reference's values.
+ */
+typedef struct {
+    pcp_intr depth;        /* depth camera intrinsics                     XPC:106            */
+    pcp_intr color;        /* colour camera intrinsics                    XPC:107            */
+    double T_d2c[16];      /* depth->colour 4x4, row-major                XPC:17-22 (f32 values widened) */
+    double ext[16];        /* base<-camera 4x4, row-major                 S1:13-18 / XPC:24-29 */
+    double ws_lo[3];       /* workspace box, strict lower bounds          DP3:29-33          */
+    double ws_hi[3];       /* workspace box, strict upper bounds          DP3:29-33          */
+    float  z_min;          /* depth validity, f32 compare  (0.01f)        XPC:109            */
+    float  z_max;          /* depth validity, f32 compare  (5.0f)         XPC:109            */
+    double zc_min;         /* colour-frame z threshold     (0.01)         XPC:75             */
+    double zc_clamp;       /* projection divisor floor     (0.001)        XPC:70-71          */
+    int32_t apply_crop;    /* 1: fuse the DP3:35-39 crop into the compaction predicate       */
+    int32_t transform_fma; /* 1: ext applied as the k-ordered FMA chain that OpenBLAS dgemm
+                              produces for XPC:119 (bit-exact vs numpy on x86-64 FMA hosts);
+                              0: ((r0*x + r1*y) + r2*z) + t with every op rounded           */
+} pcp_params;
+
+/* Reference defaults: T_DEPTH_TO_COLOR XPC:17-22, BASE_TO_EXT_CAM S1:13-18,
+ * WORK_SPACE DP3:29-33, depth range XPC:109, z thresholds XPC:70-71,75.
+ * Intrinsics are left zero (they come from the bag, XPC:37-56). */
+void pcp_default_params(pcp_params* p);
+
+const char* pcp_strerror(int status);
+/* Library version string, e.g. "pcp-hip 0.1 gfx950". */
+const char* pcp_version(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int pcp_device_count(void);
+
+/* ------------------------------------------------------------------------- *
+ * Stage 1 — replaces deproject XPC:58-64, align_colors XPC:66-78, the validity
+ * mask XPC:109, the boolean compaction XPC:110 and the rigid transform XPC:119;
+ * with p->apply_crop also the workspace crop DP3:35-42.
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Dense (un-compacted) per-pixel outputs for ONE batch of B frames; the direct
+ * counterpart of calling deproject() and align_colors() and evaluating
+ * XPC:109.  Any output pointer may be NULL.
+ *   depth     (B,H,W)      f32 metres
+ *   rgb       (B,Hc,Wc,3)  u8, RGB order (may be NULL when colors/proj_mask/valid are NULL)
+ *   pts_cam   (B,H*W,3)    f64   deproject()                         XPC:58-64
+ *   colors    (B,H*W,3)    f32   align_colors()[0], zero where !proj XPC:76-77
+ *   proj_mask (B,H*W)      u8    align_colors()[1]                   XPC:74-75
+ *   valid     (B,H*W)      u8    proj & depth>z_min & depth<z_max    XPC:109
+ *   pts_base  (B,H*W,3)    f64   ext @ [p,1] for every pixel         XPC:119
+ *   crop_mask (B,H*W)      u8    valid & inside workspace box        DP3:35-39
+ */
+int pcp_backproject_dense(const float* depth, const uint8_t* rgb,
+                          int B, int H, int W, int Hc, int Wc, const pcp_params* p,
+                          double* pts_cam, float* colors, uint8_t* proj_mask, uint8_t* valid,
+                          double* pts_base, uint8_t* crop_mask, void* stream);
+
+size_t pcp_backproject_workspace_bytes(int B, int H, int W);
+
+/*
+ * Fused backproject + colour-align + validity (+ crop) + order-preserving
+ * compaction for B frames.  Surviving points keep row-major pixel order
+ * (numpy boolean-mask order, XPC:110 / DP3:41), frames are concatenated CSR
+ * style: frame b owns rows [offsets[b], offsets[b+1]).
+ *   xyz_cam64 (cap,3) f64  camera-frame points   (pts_v,  XPC:110)   or NULL
+ *   xyz64     (cap,3) f64  base-frame points     (pts_g,  XPC:119)   or NULL
+ *   xyz32     (cap,3) f32  float32(xyz64), the FPS input (DP3:10)    or NULL
+ *   rgb32     (cap,3) f32  colours in [0,1]      (clrs_v, XPC:110)   or NULL
+ *   pix       (cap)   i32  source pixel index v*W+u                  or NULL
+ *   offsets   (B+1)   i64  CSR row offsets (written)
+ * `cap` is the row capacity of the output arrays.  If the batch produces more
+ * rows than `cap`, rows beyond cap are NOT written, offsets still hold the true
+ * counts, and `overflow` (device i32, may be NULL) is set to 1.
+ */
+int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb,
+                               int B, int H, int W, int Hc, int Wc, const pcp_params* p,
+                               double* xyz_cam64, double* xyz64, float* xyz32, float* rgb32,
+                               int32_t* pix, int64_t* offsets, int64_t cap, int32_t* overflow,
+                               void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Stage 2 — replaces process_point_cloud DP3:23-52.
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Workspace crop on already-transformed points (the PLY-input drop-in path):
+ * six strict f64 compares, DP3:35-39.
+ *   xyz   (M1,3) f64       mask (M1) u8 written       count (1) i64 written (may be NULL)
+ */
+int pcp_crop_mask(const double* xyz, int64_t M1, const double lo[3], const double hi[3],
+                  uint8_t* mask, int64_t* count, void* stream);
+
+/*
+ * Order-preserving crop + compaction of one cloud, DP3:35-42 (+ the .float()
+ * cast of DP3:10 for xyz32).
+ *   xyz (M1,3) f64, rgb (M1,3) f64 (may be NULL)
+ *   out_xyz64 (cap,3) f64 or NULL, out_xyz32 (cap,3) f32 or NULL, out_rgb64 (cap,3) f64 or NULL
+ *   count (1) i64 written: number of surviving rows (true count even if > cap)
+ */
+size_t pcp_crop_workspace_bytes(int64_t M1);
+int pcp_crop_compact(const double* xyz, const double* rgb, int64_t M1,
+                     const double lo[3], const double hi[3],
+                     double* out_xyz64, float* out_xyz32, double* out_rgb64,
+                     int64_t cap, int64_t* count, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Batched farthest-point sampling — replaces farthest_point_sampling DP3:7-21,
+ * i.e. pytorch3d.ops.sample_farthest_points(points=(1,M,3) f32, K=[K]) with
+ * random_start_point=False (contract: SURVEY.md §8c).
+ *   xyz     (total,3) f32   concatenated clouds
+ *   offsets (B+1)     i64   CSR: cloud b = rows [offsets[b], offsets[b+1])
+ *   idx     (B,K)     i64   written; index RELATIVE to the cloud's first row; -1 beyond M
+ *   out_xyz (B,K,3)   f32   written; xyz[idx], 0 where idx = -1; may be NULL
+ *   dist_mode 0: ((dx*dx)+(dy*dy))+(dz*dz), every op rounded to f32 (x86 CPU build of pytorch3d)
+ *             1: fmaf(dz,dz,fmaf(dy,dy,dx*dx))   (what nvcc's default contraction emits)
+ *   algo      0: auto   1: brute force (every point every round)
+ *             2: exact bucket-pruned FPS (same indices, far fewer distance evaluations)
+ * `max_pts` is an upper bound on the largest cloud (host-known, e.g. H*W); it
+ * sizes the launch, not the result.
+ * Ties are broken toward the lowest index; idx[b][0] = 0.  Empty clouds give
+ * an all -1 row (the reference raises inside pytorch3d; the Python wrapper
+ * raises too).
+ */
+size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo);
+int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
+                    int64_t max_pts, int K, int dist_mode, int algo,
+                    int64_t* idx, float* out_xyz, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Colour gather pc_rgb[idx], DP3:48.
+ *   rgb (total,3) f32, offsets (B+1) i64, idx (B,K) i64, out (B,K,3) f32
+ *   compat_neg_index 1: idx = -1 selects the cloud's LAST row (numpy negative
+ *                       indexing, exactly what DP3:48 does with pytorch3d's padding)
+ *                    0: idx = -1 yields zeros
+ */
+int pcp_gather_rgb(const float* rgb, const int64_t* offsets, const int64_t* idx, int B, int K,
+                   int compat_neg_index, float* out, void* stream);
+
+/*
+ * (K,6) rows exactly as chunking_data.py:134-144 stacks them for the zarr
+ * `data/point_cloud` array (CHK:195): [x, y, z, r*255, g*255, b*255] as f32.
+ *   xyz (B,K,3) f32, rgb (B,K,3) f32 in [0,1] → out (B,K,6) f32
+ * Colours pass through the PLY uchar quantisation the file round trip applies
+ * (round(clamp(c,0,1)*255)) so the values equal what CHK reads.
+ */
+int pcp_pack_dp3(const float* xyz, const float* rgb, int B, int K, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCP_H */

@@ -1,0 +1,247 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * Plain-C restatement of the reference's DP3 preprocessing hot path.  It is the
+ * parity checker for the HIP library and the timed `cpu_baseline` ("port") in
+ * bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load it; the product (point-cloud-processing_amd/) never does.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma).  -ffp-contract=off
+ * keeps every written operation individually rounded; fma()/fmaf() appear only
+ * where written.
+ *
+ * Reference files (under /root/reference/data_processing_pipeline/):
+ *   XPC = extract_point_clouds_one_cam.py   DP3 = dp3_point_cloud_processing.py
+ *
+ * Pinning: the stage-1 functions are checked bit-exact against golden vectors made
+ * by importing the reference's own deproject/align_colors (tests/golden).  FPS is
+ * PARITY UNPINNED by the reference: its arithmetic is pytorch3d's
+ * sample_farthest_points (requirements.txt:10, unpinned, absent); this restates the
+ * published algorithm and the call site DP3:7-21.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+typedef struct { double fx, fy, cx, cy; } orc_intr;
+
+typedef struct {
+    orc_intr depth, color;
+    double T_d2c[16];
+    double ext[16];
+    double ws_lo[3], ws_hi[3];
+    float z_min, z_max;
+    double zc_min, zc_clamp;
+    int32_t apply_crop;
+    int32_t transform_fma;
+} orc_params;   /* same layout as pcp_params (include/pcp.h) */
+
+/* XPC:119 for one point.  fma chain == what OpenBLAS' x86-64 FMA dgemm kernels give. */
+static inline void orc_rigid(const double* e, int use_fma, double x, double y, double z, double* o)
+{
+    for (int c = 0; c < 3; ++c) {
+        const double* r = e + 4 * c;
+        double a;
+        if (use_fma) {
+            a = r[0] * x;
+            a = fma(r[1], y, a);
+            a = fma(r[2], z, a);
+            a = fma(r[3], 1.0, a);
+        } else {
+            a = ((r[0] * x + r[1] * y) + r[2] * z) + r[3];
+        }
+        o[c] = a;
+    }
+}
+
+/*
+ * One pixel of deproject XPC:58-64 + align_colors XPC:66-78 + XPC:109.
+ * Returns bit flags: 1 = proj_mask, 2 = valid (proj & depth range).
+ */
+static inline int orc_pixel(const orc_params* P, float d, int u, int v,
+                            const uint8_t* rgb, int Hc, int Wc,
+                            double cam[3], float col[3])
+{
+    double z = (double)d;
+    cam[0] = (((double)u - P->depth.cx) * z) / P->depth.fx;       /* XPC:62 */
+    cam[1] = (((double)v - P->depth.cy) * z) / P->depth.fy;       /* XPC:63 */
+    cam[2] = z;
+    /* XPC:67-68: T @ [p,1] — general 4x4, k-ordered like the base transform */
+    double cf[3];
+    orc_rigid(P->T_d2c, 1, cam[0], cam[1], cam[2], cf);
+    double zdiv = cf[2] > P->zc_clamp ? cf[2] : P->zc_clamp;      /* np.maximum(z, 0.001) */
+    if (cf[2] != cf[2]) zdiv = cf[2];                             /* np.maximum propagates NaN */
+    double uc = ((cf[0] * P->color.fx) / zdiv) + P->color.cx;     /* XPC:70 */
+    double vc = ((cf[1] * P->color.fy) / zdiv) + P->color.cy;     /* XPC:71 */
+    double ur = rint(uc), vr = rint(vc);                          /* half-to-even, XPC:73 */
+    int inside = (ur >= 0.0) && (ur < (double)Wc) && (vr >= 0.0) && (vr < (double)Hc);
+    int proj = inside && (cf[2] > P->zc_min);                     /* XPC:74-75 */
+    col[0] = col[1] = col[2] = 0.0f;
+    if (proj && rgb) {
+        const uint8_t* px = rgb + ((size_t)(int64_t)vr * Wc + (size_t)(int64_t)ur) * 3;
+        for (int c = 0; c < 3; ++c) col[c] = (float)((double)px[c] / 255.0);   /* XPC:77 */
+    }
+    int valid = proj && (d > P->z_min) && (d < P->z_max);         /* XPC:109, f32 compares */
+    return proj | (valid << 1);
+}
+
+static inline int orc_in_box(const double* lo, const double* hi, const double* p)
+{
+    return p[0] > lo[0] && p[0] < hi[0] && p[1] > lo[1] && p[1] < hi[1] &&
+           p[2] > lo[2] && p[2] < hi[2];                          /* DP3:35-39 */
+}
+
+/* Dense per-pixel outputs for one frame; any output may be NULL. */
+void orc_backproject_dense(const float* depth, const uint8_t* rgb, int H, int W, int Hc, int Wc,
+                           const orc_params* P, double* pts_cam, float* colors,
+                           uint8_t* proj_mask, uint8_t* valid, double* pts_base, uint8_t* crop_mask)
+{
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            size_t i = (size_t)v * W + u;
+            double cam[3], g[3];
+            float col[3];
+            int f = orc_pixel(P, depth[i], u, v, rgb, Hc, Wc, cam, col);
+            orc_rigid(P->ext, P->transform_fma, cam[0], cam[1], cam[2], g);
+            if (pts_cam) memcpy(pts_cam + 3 * i, cam, sizeof cam);
+            if (colors) memcpy(colors + 3 * i, col, sizeof col);
+            if (proj_mask) proj_mask[i] = (uint8_t)(f & 1);
+            if (valid) valid[i] = (uint8_t)((f >> 1) & 1);
+            if (pts_base) memcpy(pts_base + 3 * i, g, sizeof g);
+            if (crop_mask) crop_mask[i] = (uint8_t)(((f >> 1) & 1) && orc_in_box(P->ws_lo, P->ws_hi, g));
+        }
+}
+
+/*
+ * One frame of the fused path: compacted rows in row-major pixel order.
+ * Returns the number of surviving rows (outputs must hold H*W rows).
+ */
+int64_t orc_backproject_align_crop(const float* depth, const uint8_t* rgb, int H, int W, int Hc,
+                                   int Wc, const orc_params* P, double* xyz_cam64, double* xyz64,
+                                   float* xyz32, float* rgb32, int32_t* pix)
+{
+    int64_t n = 0;
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            size_t i = (size_t)v * W + u;
+            double cam[3], g[3];
+            float col[3];
+            int f = orc_pixel(P, depth[i], u, v, rgb, Hc, Wc, cam, col);
+            if (!(f & 2)) continue;
+            orc_rigid(P->ext, P->transform_fma, cam[0], cam[1], cam[2], g);
+            if (P->apply_crop && !orc_in_box(P->ws_lo, P->ws_hi, g)) continue;
+            if (xyz_cam64) memcpy(xyz_cam64 + 3 * n, cam, sizeof cam);
+            if (xyz64) memcpy(xyz64 + 3 * n, g, sizeof g);
+            if (xyz32) for (int c = 0; c < 3; ++c) xyz32[3 * n + c] = (float)g[c];   /* DP3:10 */
+            if (rgb32) memcpy(rgb32 + 3 * n, col, sizeof col);
+            if (pix) pix[n] = (int32_t)i;
+            ++n;
+        }
+    return n;
+}
+
+/* DP3:35-39 on an (M1,3) f64 array. Returns the number of ones. */
+int64_t orc_crop_mask(const double* xyz, int64_t M1, const double* lo, const double* hi, uint8_t* mask)
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < M1; ++i) {
+        int in = orc_in_box(lo, hi, xyz + 3 * i);
+        mask[i] = (uint8_t)in;
+        n += in;
+    }
+    return n;
+}
+
+/*
+ * DP3:7-21 → pytorch3d sample_farthest_points on one cloud (M,3) f32.
+ * idx (K) int64, -1 beyond M; out_xyz (K,3) zeros beyond M (may be NULL).
+ * dist_mode 0: ((dx*dx)+(dy*dy))+(dz*dz); 1: fmaf(dz,dz,fmaf(dy,dy,dx*dx)).
+ * Strict '>' scan from p = 0 ⇒ lowest index wins ties (== cub::ArgMax on CUDA).
+ * `scratch` holds M floats.
+ */
+void orc_fps(const float* xyz, int64_t M, int K, int dist_mode, int64_t* idx, float* out_xyz,
+             float* scratch)
+{
+    for (int k = 0; k < K; ++k) idx[k] = -1;
+    if (out_xyz) memset(out_xyz, 0, sizeof(float) * 3 * (size_t)K);
+    if (M <= 0 || K <= 0) return;
+    for (int64_t p = 0; p < M; ++p) scratch[p] = FLT_MAX;
+    int64_t last = 0;
+    idx[0] = 0;
+    int64_t kn = K < M ? K : M;
+    for (int64_t k = 1; k < kn; ++k) {
+        const float sx = xyz[3 * last], sy = xyz[3 * last + 1], sz = xyz[3 * last + 2];
+        float best = -1.0f;
+        int64_t besti = 0;
+        if (dist_mode == 0) {
+            for (int64_t p = 0; p < M; ++p) {
+                float dx = sx - xyz[3 * p], dy = sy - xyz[3 * p + 1], dz = sz - xyz[3 * p + 2];
+                float d = ((dx * dx) + (dy * dy)) + (dz * dz);
+                float m = scratch[p];
+                m = d < m ? d : m;                     /* std::min(d, m) */
+                scratch[p] = m;
+                if (m > best) { best = m; besti = p; }
+            }
+        } else {
+            for (int64_t p = 0; p < M; ++p) {
+                float dx = sx - xyz[3 * p], dy = sy - xyz[3 * p + 1], dz = sz - xyz[3 * p + 2];
+                float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                float m = scratch[p];
+                m = d < m ? d : m;
+                scratch[p] = m;
+                if (m > best) { best = m; besti = p; }
+            }
+        }
+        last = besti;
+        idx[k] = last;
+    }
+    if (out_xyz)
+        for (int64_t k = 0; k < kn; ++k)
+            memcpy(out_xyz + 3 * k, xyz + 3 * idx[k], 3 * sizeof(float));
+}
+
+/* DP3:48 with numpy negative indexing for the -1 padding. */
+void orc_gather_rgb(const float* rgb, int64_t M, const int64_t* idx, int K, int compat_neg,
+                    float* out)
+{
+    for (int k = 0; k < K; ++k) {
+        int64_t i = idx[k];
+        if (i < 0) {
+            if (compat_neg && M > 0) i += M;
+            else { out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = 0.0f; continue; }
+        }
+        memcpy(out + 3 * k, rgb + 3 * i, 3 * sizeof(float));
+    }
+}
+
+/* CHK:134-144 rows: [x,y,z, 255*roundtrip(r,g,b)] as f32. */
+void orc_pack_dp3(const float* xyz, const float* rgb, int64_t n, float* out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 3; ++c) out[6 * i + c] = (float)(double)xyz[3 * i + c];
+        for (int c = 0; c < 3; ++c) {
+            double v = (double)rgb[3 * i + c];
+            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+            double q = rint(v * 255.0);
+            out[6 * i + 3 + c] = (float)((q / 255.0) * 255.0);
+        }
+    }
+}
+
+/*
+ * The whole per-frame path for the CPU baseline: stage 1 (+crop) → FPS → gather.
+ * Buffers xyz32/rgb32 hold H*W rows, scratch H*W floats. Returns M (cropped count).
+ */
+int64_t orc_frame_pipeline(const float* depth, const uint8_t* rgb, int H, int W, int Hc, int Wc,
+                           const orc_params* P, int K, int dist_mode, float* xyz32, float* rgb32,
+                           float* scratch, int64_t* idx, float* out_xyz, float* out_rgb)
+{
+    orc_params Q = *P;
+    Q.apply_crop = 1;
+    int64_t M = orc_backproject_align_crop(depth, rgb, H, W, Hc, Wc, &Q, NULL, NULL, xyz32, rgb32, NULL);
+    orc_fps(xyz32, M, K, dist_mode, idx, out_xyz, scratch);
+    orc_gather_rgb(rgb32, M, idx, K, 1, out_rgb);
+    return M;
+}

@@ -1,0 +1,183 @@
+"""CPU: the oracle (numpy restatement + C restatement) against golden vectors produced by
+the reference's own deproject/align_colors (tests/golden/make_golden.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import cbind, numpy_ref as R
+from helpers import load_npz, load_digests, intr_dict, synth_frame
+
+FIXTURES = ["stage1_48x64.npz", "stage1_64x96_c40x60.npz", "stage1_edge_32x32.npz"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_numpy_restatement_matches_reference(name):
+    g = load_npz(name)
+    d, c = intr_dict(g["dintr"]), intr_dict(g["cintr"])
+    with np.errstate(all="ignore"):
+        out = R.stage1_frame(g["depth"], g["rgb"], d, c, g["T"], g["ext"])
+    assert out["pts_cam"].dtype == np.float64 and out["colors"].dtype == np.float32
+    np.testing.assert_array_equal(out["pts_cam"], g["pts_cam"])
+    np.testing.assert_array_equal(out["colors"], g["colors"])
+    np.testing.assert_array_equal(out["proj_mask"], g["proj_mask"])
+    np.testing.assert_array_equal(out["mask"], g["mask"])
+    np.testing.assert_array_equal(out["pts_g"], g["pts_g"])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_c_oracle_matches_reference(name):
+    g = load_npz(name)
+    d, c = intr_dict(g["dintr"]), intr_dict(g["cintr"])
+    p = cbind.make_params(d, c, T=g["T"], ext=g["ext"], apply_crop=0, transform_fma=1)
+    dense = cbind.backproject_dense(g["depth"], g["rgb"], p)
+    np.testing.assert_array_equal(dense["pts_cam"], g["pts_cam"])          # bit-exact, NaN==NaN
+    np.testing.assert_array_equal(dense["colors"], g["colors"])
+    np.testing.assert_array_equal(dense["proj_mask"].astype(bool), g["proj_mask"])
+    np.testing.assert_array_equal(dense["valid"].astype(bool), g["mask"])
+    comp = cbind.backproject_align_crop(g["depth"], g["rgb"], p)
+    np.testing.assert_array_equal(comp["xyz_cam64"], g["pts_cam"][g["mask"]])
+    np.testing.assert_array_equal(comp["rgb32"], g["colors"][g["mask"]])
+    np.testing.assert_array_equal(comp["pix"], np.nonzero(g["mask"])[0])
+    # XPC:119 goes through BLAS; the k-ordered FMA chain reproduces it bit for bit here
+    np.testing.assert_array_equal(comp["xyz64"], g["pts_g"])
+    np.testing.assert_array_equal(comp["xyz32"], g["pts_g"].astype(np.float32))
+
+
+def test_c_oracle_nofma_transform_within_1ulp():
+    g = load_npz("stage1_48x64.npz")
+    d, c = intr_dict(g["dintr"]), intr_dict(g["cintr"])
+    p = cbind.make_params(d, c, T=g["T"], ext=g["ext"], transform_fma=0)
+    comp = cbind.backproject_align_crop(g["depth"], g["rgb"], p)
+    np.testing.assert_array_equal(comp["xyz64"], R.to_base_nofma(g["pts_cam"][g["mask"]], g["ext"]))
+    # both orders agree to 1e-12 absolute on metre-scale coordinates
+    np.testing.assert_allclose(comp["xyz64"], g["pts_g"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("key", ["seed0_480x640", "seed1_480x640"])
+def test_full_frame_digests(key):
+    dg = load_digests()[key]
+    depth, rgb = synth_frame(dg["seed"], dg["H"], dg["W"])
+    assert sha(depth) == dg["depth_sha"] and sha(rgb) == dg["rgb_sha"]
+    intr = dict(fx=dg["f"], fy=dg["f"], cx=dg["W"] / 2, cy=dg["H"] / 2)
+    p = cbind.make_params(intr, intr, apply_crop=0, transform_fma=1)
+    dense = cbind.backproject_dense(depth, rgb, p)
+    assert sha(dense["pts_cam"]) == dg["pts_cam_sha"]
+    assert sha(dense["colors"]) == dg["colors_sha"]
+    assert sha(dense["proj_mask"]) == dg["proj_mask_sha"]
+    assert sha(dense["valid"]) == dg["mask_sha"]
+    comp = cbind.backproject_align_crop(depth, rgb, p)
+    assert comp["xyz64"].shape[0] == dg["M1"]
+    assert sha(comp["xyz64"]) == dg["pts_g_sha"]
+
+
+def test_full_frame_digest_numpy_restatement():
+    dg = load_digests()["seed0_480x640"]
+    depth, rgb = synth_frame(dg["seed"], dg["H"], dg["W"])
+    intr = dict(fx=dg["f"], fy=dg["f"], cx=dg["W"] / 2, cy=dg["H"] / 2)
+    out = R.stage1_frame(depth, rgb, intr, intr)
+    assert sha(out["pts_cam"]) == dg["pts_cam_sha"]
+    assert sha(out["colors"]) == dg["colors_sha"]
+    assert sha(out["mask"].astype(np.uint8)) == dg["mask_sha"]
+    assert sha(out["pts_g"]) == dg["pts_g_sha"]
+
+
+def test_crop_mask_strict_and_c_equals_numpy():
+    lo = [w[0] for w in R.WORK_SPACE]
+    hi = [w[1] for w in R.WORK_SPACE]
+    pts = np.array([[0.1, 0.1, 0.1],            # inside
+                    [-0.05, 0.1, 0.1],          # on the x-low face: strict → out
+                    [0.4, 0.1, 0.1],            # on the x-high face → out
+                    [np.nextafter(-0.05, 1), 0.1, 0.1],   # one ulp inside
+                    [0.1, np.nextafter(0.35, 0), 0.1],
+                    [0.1, 0.35, 0.1],
+                    [0.1, 0.1, -0.008],
+                    [0.1, 0.1, np.nextafter(0.6, 0)],
+                    [np.nan, 0.1, 0.1]], dtype=np.float64)
+    expect = np.array([1, 0, 0, 1, 1, 0, 0, 1, 0], dtype=bool)
+    np.testing.assert_array_equal(R.crop_mask(pts), expect)
+    np.testing.assert_array_equal(cbind.crop_mask(pts, lo, hi), expect)
+    rng = np.random.default_rng(3)
+    big = rng.uniform(-0.3, 0.8, (20000, 3))
+    np.testing.assert_array_equal(cbind.crop_mask(big, lo, hi), R.crop_mask(big))
+
+
+# ---- FPS known-answer cases (hand-derived; pytorch3d itself is absent: parity unpinned) ----
+
+def _both_fps(pts, K):
+    s0, i0 = R.fps(pts, K)
+    s1, i1 = cbind.fps(pts, K, 0)
+    np.testing.assert_array_equal(i0, i1)
+    np.testing.assert_array_equal(s0, s1)
+    return s0, i0
+
+
+def test_fps_collinear():
+    pts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [3, 0, 0], [10, 0, 0]], dtype=np.float64)
+    _, idx = _both_fps(pts, 4)
+    # start 0 → farthest 10 (idx 4) → then min-dist: 1→1, 2→4, 3→9 → idx 3 → then 1→1, 2→1 tie → lowest idx 1
+    assert idx.tolist() == [0, 4, 3, 1]
+
+
+def test_fps_cube_corners_and_centre():
+    corners = [[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)]
+    pts = np.array(corners + [[0.5, 0.5, 0.5]], dtype=np.float64)
+    _, idx = _both_fps(pts, 9)
+    # from corner 000: farthest is 111 (idx 7); then six corners tie at d=1... (min of 1/2 and 2/1):
+    # corners with one coordinate set have min(1,2)=1; two set: min(2,1)=1; centre 0.75 → lowest idx 1
+    assert idx[:3].tolist() == [0, 7, 1]
+    assert sorted(idx.tolist()) == list(range(9))
+    assert idx[-1] == 8          # the centre is always closest to something: picked last
+
+
+def test_fps_duplicates_tie_to_index_zero():
+    pts = np.zeros((6, 3))
+    _, idx = _both_fps(pts, 4)
+    assert idx.tolist() == [0, 0, 0, 0]
+
+
+def test_fps_padding_and_gather_compat():
+    pts = np.array([[0, 0, 0], [3, 0, 0], [1, 0, 0]], dtype=np.float64)
+    s, idx = _both_fps(pts, 5)
+    assert idx.tolist() == [0, 1, 2, -1, -1]
+    np.testing.assert_array_equal(s[3:], 0)
+    rgb = np.array([[.1, .2, .3], [.4, .5, .6], [.7, .8, .9]], dtype=np.float32)
+    np.testing.assert_array_equal(R.gather_rgb(rgb, idx)[3], rgb[-1])      # DP3:48 negative index
+    np.testing.assert_array_equal(cbind.gather_rgb(rgb, idx, 1), R.gather_rgb(rgb, idx))
+    np.testing.assert_array_equal(cbind.gather_rgb(rgb, idx, 0)[3:], 0)
+
+
+def test_fps_single_point_and_random_agreement():
+    _, idx = _both_fps(np.array([[1.0, 2.0, 3.0]]), 3)
+    assert idx.tolist() == [0, -1, -1]
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-1, 1, (3000, 3))
+    s, idx = _both_fps(pts, 200)
+    assert idx[0] == 0 and len(set(idx.tolist())) == 200
+    # min-distance of each pick to the earlier picks is non-increasing
+    p32 = pts.astype(np.float32)
+    prev = np.inf
+    for k in range(1, 200):
+        d = ((p32[idx[:k]] - p32[idx[k]]) ** 2).sum(1).min()
+        assert d <= prev * (1 + 1e-6)
+        prev = d
+
+
+def test_fps_fma_mode_close_to_nofma():
+    rng = np.random.default_rng(6)
+    pts = rng.uniform(-1, 1, (2000, 3))
+    _, i0 = cbind.fps(pts, 128, 0)
+    _, i1 = cbind.fps(pts, 128, 1)
+    assert i0[0] == i1[0] == 0 and (i0 == i1).mean() > 0.9
+
+
+def test_pack_dp3_matches_chunking_restatement():
+    rng = np.random.default_rng(7)
+    xyz = rng.uniform(-1, 1, (50, 3)).astype(np.float32)
+    rgb = (rng.integers(0, 256, (50, 3)) / 255.0).astype(np.float32)
+    np.testing.assert_array_equal(cbind.pack_dp3(xyz, rgb), R.dp3_rows(xyz, rgb))
+    np.testing.assert_array_equal(cbind.pack_dp3(xyz, rgb)[:, 3:], np.rint(rgb * 255))

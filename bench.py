@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""
+bench.py — frames/sec of the DP3 hot path (640x480 depth+RGB → backproject → crop → 1024-pt
+FPS → colour gather) on N MI355X, one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over ONE synthetic 300-frame episode that is already
+resident in HBM (BASELINE.json configs[1]).  Every rank owns its own episode (weak scaling,
+no data-path collective: frames are independent); the only collectives are the
+timing barrier and the max-over-ranks reduction.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "point-cloud-processing_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+
+H, W, K_FPS, FRAMES = 480, 640, 1024, 300
+BYTES_PER_FRAME = H * W * (4 + 3) + K_FPS * (12 + 12 + 8)      # 2,183,168 B
+HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(budget_s=12.0, max_frames=64):
+    """The C oracle ("port" of the reference's per-frame path) on this box's host cores,
+    single thread like the reference's serial loops, on a bounded sample of the same episode."""
+    from oracle import cbind
+    from pcp import synth
+    intr = synth.intrinsics(H, W)
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    cbind.frame_pipeline(*synth.frame(10_000, H, W), po, K_FPS, 0)       # warm (page in, build)
+    n, t_total = 0, 0.0
+    while n < max_frames and t_total < budget_s:
+        d, c = synth.frame(n, H, W)
+        t0 = time.perf_counter()
+        cbind.frame_pipeline(d, c, po, K_FPS, 0)
+        t_total += time.perf_counter() - t0
+        n += 1
+    return {"value": n / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} frames of the same synthetic episode (seeds 0..{n - 1}), "
+                      f"C oracle -O2 -ffp-contract=off, stage1+crop+FPS+gather, {t_total:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=FRAMES, help="frames per episode (default 300)")
+    ap.add_argument("--algo", type=int, default=0, help="FPS algorithm (0 auto, 1 brute, 2 bucket)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pcp import _ffi, ops, synth
+    intr = synth.intrinsics(H, W)
+    params = _ffi.make_params(intr, intr, apply_crop=True)
+    B = args.frames
+    depth_h, rgb_h = synth.episode(B, seed0=rank * 1000, H=H, W=W)   # rank r = episode r
+    depth = torch.from_numpy(depth_h).to(dev)
+    rgb = torch.from_numpy(rgb_h).to(dev)
+    del depth_h, rgb_h
+    pipe = ops.FramePipeline(B, H, W, K_FPS, params, dev, dist_mode=0, algo=args.algo)
+
+    L = _ffi.load_library()
+    ptr, stream = ops._ptr, ops._stream
+    f = pipe.fps
+
+    def step(ev=None):
+        out, offsets = pipe.stage1.run(depth, rgb, params)
+        if ev is not None:
+            ev[0].record()
+        _ffi.check(L.pcp_fps_batched(ptr(out["xyz32"]), ptr(offsets), f.B, pipe.stage1.cap, f.max_pts,
+                                     f.K, f.dist_mode, f.algo, ptr(f.idx), ptr(f.xyz), ptr(f.ws),
+                                     f.ws_bytes, stream()))
+        if ev is not None:
+            ev[1].record()
+        _ffi.check(L.pcp_gather_rgb(ptr(out["rgb32"]), ptr(offsets), ptr(f.idx), f.B, f.K, 1,
+                                    ptr(pipe.rgb_out), stream()))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fps_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)   # dominant kernel(s)
+    off = pipe.stage1.offsets.cpu().numpy()
+    m_mean = float(np.diff(off).mean())
+    assert int(pipe.stage1.overflow.item()) == 0
+    assert int(pipe.fps.idx.min().item()) >= 0, "FPS produced padding on a bench frame"
+
+    if rank == 0:
+        total_frames = B * world * args.steps
+        value = total_frames / elapsed
+        achieved = (B * BYTES_PER_FRAME) / (fps_ms * 1e-3) / 1e9 if fps_ms > 0 else 0.0
+        line = {
+            "metric": "frames/sec (640x480 depth -> 1024-pt FPS)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 backprojection/crop, f32 FPS distances",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: one synthetic {B}-frame episode per GPU, "
+                                   f"640x480 depth+RGB -> crop -> {K_FPS}-pt FPS, resident in HBM",
+                       "frames_per_step_per_gpu": B, "K": K_FPS, "mean_points_after_crop": m_mean,
+                       "fps_algo": args.algo, "dist_mode": "nofma"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fps (pcp_fps_batched launches)", "kernel_ms_per_launch": fps_ms,
+                         "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

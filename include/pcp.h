@@ -130,10 +130,10 @@ int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb,
 /*
  * Workspace crop on already-transformed points (the PLY-input drop-in path):
  * six strict f64 compares, DP3:35-39.
- *   xyz   (M1,3) f64       mask (M1) u8 written       count (1) i64 written (may be NULL)
+ *   xyz   (M1,3) f64       mask (M1) u8 written
  */
 int pcp_crop_mask(const double* xyz, int64_t M1, const double lo[3], const double hi[3],
-                  uint8_t* mask, int64_t* count, void* stream);
+                  uint8_t* mask, void* stream);
 
 /*
  * Order-preserving crop + compaction of one cloud, DP3:35-42 (+ the .float()

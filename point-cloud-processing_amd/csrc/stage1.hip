@@ -1,0 +1,299 @@
+// Stage 1 of the DP3 path on gfx950: pinhole backprojection, colour alignment, validity
+// mask, rigid transform into the robot-base frame, optional workspace crop, and an
+// ORDER-PRESERVING stream compaction (row-major pixel order == numpy boolean-mask order).
+//
+// Replaces (reference files under data_processing_pipeline/):
+//   deproject       extract_point_clouds_one_cam.py:58-64
+//   align_colors    extract_point_clouds_one_cam.py:66-78
+//   validity mask   extract_point_clouds_one_cam.py:109-110
+//   base transform  extract_point_clouds_one_cam.py:119
+//   workspace crop  dp3_point_cloud_processing.py:35-42 (when apply_crop)
+//
+// All coordinate math is FP64 in the reference's operation order, so the
+// masks are bit-exact; the only f32 compares are the depth-range tests of XPC:109.
+//
+// Compaction is three launches with no inter-workgroup hand-off inside a launch:
+//   k1_flags   : every pixel → predicate; one 64-bit ballot per 64 consecutive pixels and
+//                one count per 1024-pixel tile                       (reads depth + rgb)
+//   k1_scan_*  : per-frame tile offsets, then CSR frame offsets      (tiny)
+//   k1_scatter : thread j of a tile finds the tile's j-th survivor from the ballots,
+//                recomputes that pixel and writes row offsets[b]+tile_off+j — only
+//                survivors cost FP64 work the second time, and rows land coalesced.
+#include "pcp_internal.h"
+
+struct PixelOut {
+    double cam[3];
+    double base[3];
+    float col[3];
+    int proj, valid, inbox, keep;
+};
+
+// rows 0..2 of a 4x4 applied to (x,y,z,1)
+__device__ __forceinline__ void rigid3(const double* r, int use_fma, double x, double y, double z,
+                                       double* o)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double* q = r + 4 * c;
+        double a;
+        if (use_fma) {                       // k-ordered chain == OpenBLAS dgemm on FMA hosts
+            a = q[0] * x;
+            a = fma(q[1], y, a);
+            a = fma(q[2], z, a);
+            a = fma(q[3], 1.0, a);
+        } else {
+            a = ((q[0] * x + q[1] * y) + q[2] * z) + q[3];
+        }
+        o[c] = a;
+    }
+}
+
+template <bool NEED_COLOR>
+__device__ __forceinline__ void pixel_math(const DevParams& P, float d, int u, int v,
+                                           const uint8_t* __restrict__ rgb, int Hc, int Wc,
+                                           PixelOut& o)
+{
+    const double z = (double)d;
+    o.cam[0] = (((double)u - P.dcx) * z) / P.dfx;                 // XPC:62 multiply, then divide
+    o.cam[1] = (((double)v - P.dcy) * z) / P.dfy;                 // XPC:63
+    o.cam[2] = z;
+    double cf[3];
+    rigid3(P.T, 1, o.cam[0], o.cam[1], o.cam[2], cf);             // XPC:67-68
+    double zdiv = cf[2] > P.zc_clamp ? cf[2] : P.zc_clamp;        // np.maximum(z, 0.001)
+    if (cf[2] != cf[2]) zdiv = cf[2];                             //   ... which propagates NaN
+    const double uc = ((cf[0] * P.cfx) / zdiv) + P.ccx;           // XPC:70
+    const double vc = ((cf[1] * P.cfy) / zdiv) + P.ccy;           // XPC:71
+    const double ur = rint(uc), vr = rint(vc);                    // half-to-even, XPC:73
+    const bool inside = (ur >= 0.0) && (ur < (double)Wc) && (vr >= 0.0) && (vr < (double)Hc);
+    o.proj = inside && (cf[2] > P.zc_min);                        // XPC:74-75
+    o.valid = o.proj && (d > P.z_min) && (d < P.z_max);           // XPC:109 (f32 compares)
+    o.col[0] = o.col[1] = o.col[2] = 0.0f;
+    if (NEED_COLOR && o.proj && rgb) {
+        const uint8_t* px = rgb + ((size_t)(long long)vr * Wc + (size_t)(long long)ur) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o.col[c] = (float)((double)px[c] / 255.0);   // XPC:77
+    }
+    rigid3(P.E, P.transform_fma, o.cam[0], o.cam[1], o.cam[2], o.base);          // XPC:119
+    const bool in_box = o.base[0] > P.lo[0] && o.base[0] < P.hi[0] &&
+                        o.base[1] > P.lo[1] && o.base[1] < P.hi[1] &&
+                        o.base[2] > P.lo[2] && o.base[2] < P.hi[2];              // DP3:35-39
+    o.inbox = o.valid && in_box;
+    o.keep = o.valid && (!P.apply_crop || in_box);
+}
+
+// ---- dense per-pixel outputs -------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k1_dense(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
+         int Wc, DevParams P, double* pts_cam, float* colors, uint8_t* proj_mask, uint8_t* valid,
+         double* pts_base, uint8_t* crop_mask)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const size_t g = (size_t)b * HW + i;
+    const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
+    PixelOut o;
+    pixel_math<true>(P, depth[g], i % W, i / W, img, Hc, Wc, o);
+    if (pts_cam) { pts_cam[3 * g] = o.cam[0]; pts_cam[3 * g + 1] = o.cam[1]; pts_cam[3 * g + 2] = o.cam[2]; }
+    if (pts_base) { pts_base[3 * g] = o.base[0]; pts_base[3 * g + 1] = o.base[1]; pts_base[3 * g + 2] = o.base[2]; }
+    if (colors) { colors[3 * g] = o.col[0]; colors[3 * g + 1] = o.col[1]; colors[3 * g + 2] = o.col[2]; }
+    if (proj_mask) proj_mask[g] = (uint8_t)o.proj;
+    if (valid) valid[g] = (uint8_t)o.valid;
+    if (crop_mask) crop_mask[g] = (uint8_t)o.inbox;
+}
+
+// ---- compaction pass 1: predicate ballots + tile counts ------------------------------------
+// grid (tiles, B), block 256: wave w, round r covers pixels tile*1024 + (w*4+r)*64 + lane.
+__global__ void __launch_bounds__(256)
+k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
+         int Wc, DevParams P, unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt,
+         int tiles)
+{
+    __shared__ int wave_cnt[4];
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int lane = pcp_lane(), wave = threadIdx.x >> 6;
+    const float* dframe = depth + (size_t)b * HW;
+    const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
+    unsigned long long* mrow = masks + ((size_t)b * tiles + tile) * PCP_TILE_WORDS;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int word = wave * 4 + r;
+        const int i = tile * PCP_TILE + word * 64 + lane;
+        int keep = 0;
+        if (i < HW) {
+            PixelOut o;
+            pixel_math<false>(P, dframe[i], i % W, i / W, img, Hc, Wc, o);
+            keep = o.keep;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) mrow[word] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) wave_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        tile_cnt[(size_t)b * tiles + tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// ---- scan kernels (shared with crop.hip) -----------------------------------------------------
+// one block per frame: exclusive prefix of the frame's tile counts (in place) + frame total
+__global__ void __launch_bounds__(256)
+pcp_scan_tiles(int* __restrict__ tile_cnt, int tiles, long long* __restrict__ frame_cnt)
+{
+    __shared__ int lds[17];
+    int* row = tile_cnt + (size_t)blockIdx.x * tiles;
+    int carry = 0;
+    for (int t0 = 0; t0 < tiles; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const int v = t < tiles ? row[t] : 0;
+        int total;
+        const int ex = pcp_block_excl_scan(v, lds, &total);
+        if (t < tiles) row[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) frame_cnt[blockIdx.x] = carry;
+}
+
+// single block: offsets[0..B] = exclusive prefix of frame_cnt (int64)
+__global__ void __launch_bounds__(256)
+pcp_scan_frames(const long long* __restrict__ frame_cnt, int B, long long* __restrict__ offsets)
+{
+    __shared__ long long wsum[4];
+    __shared__ long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = pcp_lane(), wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const long long v = b < B ? frame_cnt[b] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            long long t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const long long carry = carry_s;
+        if (b < B) offsets[b] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[B] = carry_s;
+}
+
+// ---- compaction pass 2: survivors only -----------------------------------------------------
+__global__ void __launch_bounds__(256)
+k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
+           int Wc, DevParams P, const unsigned long long* __restrict__ masks,
+           const int* __restrict__ tile_off, const long long* __restrict__ offsets, int tiles,
+           double* xyz_cam64, double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
+           long long cap, int* overflow)
+{
+    __shared__ unsigned long long m[PCP_TILE_WORDS];
+    __shared__ int pre[PCP_TILE_WORDS + 1];
+    const int b = blockIdx.y, tile = blockIdx.x;
+    if (threadIdx.x < PCP_TILE_WORDS)
+        m[threadIdx.x] = masks[((size_t)b * tiles + tile) * PCP_TILE_WORDS + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < PCP_TILE_WORDS; ++w) { pre[w] = acc; acc += __popcll(m[w]); }
+        pre[PCP_TILE_WORDS] = acc;
+    }
+    __syncthreads();
+    const int n = pre[PCP_TILE_WORDS];
+    if (n == 0) return;
+    const long long base = offsets[b] + tile_off[(size_t)b * tiles + tile];
+    const float* dframe = depth + (size_t)b * HW;
+    const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        int w = 0;
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1)
+            if (pre[w + s] <= j) w += s;            // largest w with pre[w] <= j
+        const int bit = pcp_select_bit(m[w], j - pre[w]);
+        const int i = tile * PCP_TILE + w * 64 + bit;
+        const long long row = base + j;
+        if (row >= cap) { if (overflow) *overflow = 1; continue; }
+        PixelOut o;
+        pixel_math<true>(P, dframe[i], i % W, i / W, img, Hc, Wc, o);
+        if (xyz_cam64) { xyz_cam64[3 * row] = o.cam[0]; xyz_cam64[3 * row + 1] = o.cam[1]; xyz_cam64[3 * row + 2] = o.cam[2]; }
+        if (xyz64) { xyz64[3 * row] = o.base[0]; xyz64[3 * row + 1] = o.base[1]; xyz64[3 * row + 2] = o.base[2]; }
+        if (xyz32) { xyz32[3 * row] = (float)o.base[0]; xyz32[3 * row + 1] = (float)o.base[1]; xyz32[3 * row + 2] = (float)o.base[2]; }   // DP3:10
+        if (rgb32) { rgb32[3 * row] = o.col[0]; rgb32[3 * row + 1] = o.col[1]; rgb32[3 * row + 2] = o.col[2]; }
+        if (pix) pix[row] = i;
+    }
+}
+
+// ---- host entry points -----------------------------------------------------------------------
+static bool params_ok(const pcp_params* p)
+{
+    return p && p->depth.fx != 0.0 && p->depth.fy != 0.0;
+}
+
+extern "C" int pcp_backproject_dense(const float* depth, const uint8_t* rgb, int B, int H, int W,
+                                     int Hc, int Wc, const pcp_params* p, double* pts_cam,
+                                     float* colors, uint8_t* proj_mask, uint8_t* valid,
+                                     double* pts_base, uint8_t* crop_mask, void* stream)
+{
+    if (!depth || !params_ok(p) || B < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0)
+        return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4) return PCP_ERR_INVALID_ARG;
+    if (B == 0) return PCP_OK;
+    const int HW = H * W;
+    dim3 grid((HW + 255) / 256, B);
+    hipLaunchKernelGGL(k1_dense, grid, dim3(256), 0, (hipStream_t)stream, depth, rgb, HW, W, Hc, Wc,
+                       pcp_to_dev(p), pts_cam, colors, proj_mask, valid, pts_base, crop_mask);
+    return pcp_launch_status();
+}
+
+// workspace layout: masks u64[B*tiles*16] | tile_cnt i32[B*tiles] | frame_cnt i64[B]
+extern "C" size_t pcp_backproject_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 256;
+    const size_t tiles = ((size_t)H * W + PCP_TILE - 1) / PCP_TILE;
+    return pcp_align256((size_t)B * tiles * PCP_TILE_WORDS * 8) + pcp_align256((size_t)B * tiles * 4) +
+           pcp_align256((size_t)B * 8) + 256;
+}
+
+extern "C" int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb, int B, int H, int W,
+                                          int Hc, int Wc, const pcp_params* p, double* xyz_cam64,
+                                          double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
+                                          int64_t* offsets, int64_t cap, int32_t* overflow, void* ws,
+                                          size_t ws_bytes, void* stream)
+{
+    if (!depth || !params_ok(p) || !offsets || B < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || cap < 0)
+        return PCP_ERR_INVALID_ARG;
+    if (rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4) return PCP_ERR_INVALID_ARG;
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_backproject_workspace_bytes(B, H, W))
+        return PCP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    const int tiles = (HW + PCP_TILE - 1) / PCP_TILE;
+    char* w = (char*)ws;
+    unsigned long long* masks = (unsigned long long*)w;
+    w += pcp_align256((size_t)B * tiles * PCP_TILE_WORDS * 8);
+    int* tile_cnt = (int*)w;
+    w += pcp_align256((size_t)B * tiles * 4);
+    long long* frame_cnt = (long long*)w;
+    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (B == 0) {
+        PCP_HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int64_t), st));
+        return PCP_OK;
+    }
+    const DevParams P = pcp_to_dev(p);
+    dim3 grid(tiles, B);
+    hipLaunchKernelGGL(k1_flags, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, P, masks, tile_cnt, tiles);
+    hipLaunchKernelGGL(pcp_scan_tiles, dim3(B), dim3(256), 0, st, tile_cnt, tiles, frame_cnt);
+    hipLaunchKernelGGL(pcp_scan_frames, dim3(1), dim3(256), 0, st, frame_cnt, B, (long long*)offsets);
+    hipLaunchKernelGGL(k1_scatter, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, P, masks, tile_cnt,
+                       (const long long*)offsets, tiles, xyz_cam64, xyz64, xyz32, rgb32, pix,
+                       (long long)cap, overflow);
+    return pcp_launch_status();
+}

@@ -1,0 +1,197 @@
+"""Tensor-level operators over the C ABI.  Inputs/outputs are torch ROCm tensors; every call
+enqueues on torch's current HIP stream and returns without synchronising unless noted."""
+import ctypes as C
+
+import torch
+
+from . import _ffi
+from ._ffi import check, load_library
+
+
+def _require_cuda(*tensors):
+    if not torch.cuda.is_available():
+        raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise ValueError("pcp operators take device tensors")
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _workspace(nbytes, device):
+    ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+    off = (-ws.data_ptr()) % 256
+    return ws[off:off + int(nbytes)]
+
+
+def backproject_dense(depth, rgb, params, want=("pts_cam", "colors", "proj_mask", "valid",
+                                                 "pts_base", "crop_mask")):
+    """deproject + align_colors + XPC:109/119 for every pixel of (B,H,W) depth."""
+    _require_cuda(depth, rgb)
+    _chk(depth, torch.float32, "depth"); _chk(rgb, torch.uint8, "rgb")
+    B, H, W = depth.shape
+    Hc, Wc = rgb.shape[1], rgb.shape[2]
+    dev, n = depth.device, H * W
+    spec = dict(pts_cam=((B, n, 3), torch.float64), colors=((B, n, 3), torch.float32),
+                proj_mask=((B, n), torch.uint8), valid=((B, n), torch.uint8),
+                pts_base=((B, n, 3), torch.float64), crop_mask=((B, n), torch.uint8))
+    out = {k: torch.empty(spec[k][0], dtype=spec[k][1], device=dev) for k in want}
+    g = lambda k: _ptr(out.get(k))
+    check(load_library().pcp_backproject_dense(
+        _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("pts_cam"), g("colors"),
+        g("proj_mask"), g("valid"), g("pts_base"), g("crop_mask"), _stream()))
+    return out
+
+
+class Stage1:
+    """Reusable buffers for pcp_backproject_align_crop on (B,H,W) batches."""
+
+    def __init__(self, B, H, W, device, cap=None, want=("xyz32", "rgb32")):
+        L = load_library()
+        self.B, self.H, self.W = B, H, W
+        self.cap = int(cap if cap is not None else B * H * W)
+        self.ws_bytes = L.pcp_backproject_workspace_bytes(B, H, W)
+        self.ws = _workspace(self.ws_bytes, device)
+        spec = dict(xyz_cam64=(3, torch.float64), xyz64=(3, torch.float64), xyz32=(3, torch.float32),
+                    rgb32=(3, torch.float32), pix=(0, torch.int32))
+        self.out = {}
+        for k in want:
+            c, dt = spec[k]
+            shape = (self.cap, c) if c else (self.cap,)
+            self.out[k] = torch.empty(shape, dtype=dt, device=device)
+        self.offsets = torch.zeros(B + 1, dtype=torch.int64, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def run(self, depth, rgb, params):
+        _require_cuda(depth, rgb)
+        _chk(depth, torch.float32, "depth"); _chk(rgb, torch.uint8, "rgb")
+        B, H, W = depth.shape
+        if (B, H, W) != (self.B, self.H, self.W):
+            raise ValueError("depth shape does not match the Stage1 plan")
+        Hc, Wc = rgb.shape[1], rgb.shape[2]
+        g = lambda k: _ptr(self.out.get(k))
+        check(load_library().pcp_backproject_align_crop(
+            _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("xyz_cam64"), g("xyz64"),
+            g("xyz32"), g("rgb32"), g("pix"), _ptr(self.offsets), self.cap, _ptr(self.overflow),
+            _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.out, self.offsets
+
+
+def crop_mask(xyz, lo, hi):
+    _require_cuda(xyz)
+    _chk(xyz, torch.float64, "xyz")
+    m = torch.empty(xyz.shape[0], dtype=torch.uint8, device=xyz.device)
+    lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
+    check(load_library().pcp_crop_mask(_ptr(xyz), xyz.shape[0], lo3, hi3, _ptr(m), _stream()))
+    return m
+
+
+def crop_compact(xyz, rgb, lo, hi, want_xyz64=True, want_xyz32=True):
+    """DP3:35-42 on one cloud.  Synchronises once to learn the surviving row count."""
+    _require_cuda(xyz, rgb)
+    _chk(xyz, torch.float64, "xyz")
+    if rgb is not None:
+        _chk(rgb, torch.float64, "rgb")
+    L = load_library()
+    M1, dev = xyz.shape[0], xyz.device
+    nb = L.pcp_crop_workspace_bytes(M1)
+    ws = _workspace(nb, dev)
+    o64 = torch.empty((M1, 3), dtype=torch.float64, device=dev) if want_xyz64 else None
+    o32 = torch.empty((M1, 3), dtype=torch.float32, device=dev) if want_xyz32 else None
+    orgb = torch.empty((M1, 3), dtype=torch.float64, device=dev) if rgb is not None else None
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
+    check(L.pcp_crop_compact(_ptr(xyz), _ptr(rgb), M1, lo3, hi3, _ptr(o64), _ptr(o32), _ptr(orgb),
+                             M1, _ptr(count), _ptr(ws), nb, _stream()))
+    m = int(count.item())
+    cut = lambda t: None if t is None else t[:m]
+    return cut(o64), cut(o32), cut(orgb), m
+
+
+class Fps:
+    """Reusable workspace for pcp_fps_batched."""
+
+    def __init__(self, B, total_cap, max_pts, K, device, dist_mode=0, algo=0):
+        L = load_library()
+        self.B, self.K, self.total_cap, self.max_pts = B, K, int(total_cap), int(max_pts)
+        self.dist_mode, self.algo = dist_mode, algo
+        self.ws_bytes = L.pcp_fps_workspace_bytes(B, self.total_cap, self.max_pts, K, algo)
+        self.ws = _workspace(self.ws_bytes, device)
+        self.idx = torch.empty((B, K), dtype=torch.int64, device=device)
+        self.xyz = torch.empty((B, K, 3), dtype=torch.float32, device=device)
+
+    def run(self, xyz, offsets):
+        _require_cuda(xyz, offsets)
+        _chk(xyz, torch.float32, "xyz"); _chk(offsets, torch.int64, "offsets")
+        if offsets.numel() != self.B + 1:
+            raise ValueError("offsets must have B+1 entries")
+        if xyz.shape[0] > self.total_cap:
+            raise ValueError("more points than the Fps plan was sized for")
+        check(load_library().pcp_fps_batched(
+            _ptr(xyz), _ptr(offsets), self.B, xyz.shape[0], self.max_pts, self.K, self.dist_mode,
+            self.algo, _ptr(self.idx), _ptr(self.xyz), _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.xyz, self.idx
+
+
+def fps_batched(xyz, offsets, K, dist_mode=0, algo=0, max_pts=None):
+    B = offsets.numel() - 1
+    if max_pts is None:
+        max_pts = xyz.shape[0]
+    plan = Fps(B, xyz.shape[0], max_pts, K, xyz.device, dist_mode, algo)
+    return plan.run(xyz, offsets)
+
+
+def gather_rgb(rgb, offsets, idx, compat_neg_index=True):
+    _require_cuda(rgb, offsets, idx)
+    _chk(rgb, torch.float32, "rgb"); _chk(offsets, torch.int64, "offsets"); _chk(idx, torch.int64, "idx")
+    B, K = idx.shape
+    out = torch.empty((B, K, 3), dtype=torch.float32, device=rgb.device)
+    check(load_library().pcp_gather_rgb(_ptr(rgb), _ptr(offsets), _ptr(idx), B, K,
+                                        1 if compat_neg_index else 0, _ptr(out), _stream()))
+    return out
+
+
+def pack_dp3(xyz, rgb):
+    _require_cuda(xyz, rgb)
+    _chk(xyz, torch.float32, "xyz"); _chk(rgb, torch.float32, "rgb")
+    B, K = xyz.shape[0], xyz.shape[1]
+    out = torch.empty((B, K, 6), dtype=torch.float32, device=xyz.device)
+    check(load_library().pcp_pack_dp3(_ptr(xyz), _ptr(rgb), B, K, _ptr(out), _stream()))
+    return out
+
+
+class FramePipeline:
+    """The whole hot path for batches of B frames: depth+rgb → (B,K,3) xyz, (B,K,3) rgb,
+    (B,K) idx.  All buffers are allocated once; run() only enqueues kernels."""
+
+    def __init__(self, B, H, W, K, params, device="cuda", dist_mode=0, algo=0, cap_per_frame=None):
+        self.B, self.H, self.W, self.K, self.params = B, H, W, K, params
+        cap = B * (cap_per_frame if cap_per_frame is not None else H * W)
+        self.stage1 = Stage1(B, H, W, device, cap=cap, want=("xyz32", "rgb32"))
+        self.fps = Fps(B, cap, H * W, K, device, dist_mode, algo)
+        self.rgb_out = torch.empty((B, K, 3), dtype=torch.float32, device=device)
+
+    def run(self, depth, rgb):
+        out, offsets = self.stage1.run(depth, rgb, self.params)
+        L = load_library()
+        f = self.fps
+        check(L.pcp_fps_batched(_ptr(out["xyz32"]), _ptr(offsets), f.B, self.stage1.cap, f.max_pts, f.K,
+                                f.dist_mode, f.algo, _ptr(f.idx), _ptr(f.xyz), _ptr(f.ws), f.ws_bytes,
+                                _stream()))
+        check(L.pcp_gather_rgb(_ptr(out["rgb32"]), _ptr(offsets), _ptr(f.idx), f.B, f.K, 1,
+                               _ptr(self.rgb_out), _stream()))
+        return f.xyz, self.rgb_out, f.idx, offsets

@@ -88,12 +88,326 @@ fps_brute(const float* __restrict__ xyz, const long long* __restrict__ offsets, 
     }
 }
 
+// ---- exact bucket-pruned FPS ------------------------------------------------------------------
+// Same picks as the brute-force scan, far fewer distance evaluations (≈20-35·M instead of
+// (K-1)·M on the benchmark frames).  One workgroup owns one cloud:
+//   prologue  bounding box → uniform grid of ≤ T*CPT cells → LDS counting sort of the points
+//             into {x,y,z,orig_idx} records grouped by cell (+ one min_d float per point);
+//             thread t owns cells t, t+T, … and keeps their tight boxes in registers.
+//   round     A  every owner tests its cells: lb = dist2(s, clamp(s, box)).  The same rounded
+//                operation sequence as the point distance and monotone rounding give
+//                lb <= dist2(s,p) for every p in the box, so a cell with lb >= cell_max cannot
+//                change and is skipped; the others are queued.  The arg-max over the owner's
+//                skipped cells is reduced per wave.
+//             B  waves drain the queue: one cell = ≤64 points per step, min_d updated in
+//                place, new (cell_max, lowest index, xyz) written to LDS.
+//             C  arg-max over the 2*NW wave partials gives the next sample and its xyz
+//                without touching global memory.
+// Two workgroup barriers and one global-memory round trip per round.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// wave-uniform maximum of one u32 per lane (DPP butterfly, no LDS traffic)
+__device__ __forceinline__ unsigned wave_umax_u32(unsigned v)
+{
+    v = max(v, dpp_u32<0xB1>(v));          // quad_perm [1,0,3,2]
+    v = max(v, dpp_u32<0x4E>(v));          // quad_perm [2,3,0,1]
+    v = max(v, dpp_u32<0x141>(v));         // row_half_mirror
+    v = max(v, dpp_u32<0x140>(v));         // row_mirror: every lane of a row holds the row max
+    v = max(v, dpp_u32<0x142, 0xA>(v));    // row_bcast15 → rows 1,3
+    v = max(v, dpp_u32<0x143, 0xC>(v));    // row_bcast31 → rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// wave-uniform maximum of one u64 key per lane
+__device__ __forceinline__ unsigned long long wave_umax_key(unsigned long long k)
+{
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned m = wave_umax_u32(hi);
+    const unsigned l = wave_umax_u32(hi == m ? lo : 0u);
+    return ((unsigned long long)m << 32) | l;
+}
+
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+__device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int g)
+{
+    int c = (int)((v - lo) * inv_h);
+    return min(g - 1, max(0, c));
+}
+
+#define PCP_BUCKET_TARGET_PTS 16       // aim for about this many points per cell
+
+template <int T, int CPT>
+constexpr size_t fps_bucket_lds_bytes()
+{
+    constexpr size_t CMAX = (size_t)T * CPT, NW = T / 64;
+    return CMAX * 8 + CMAX * 12 + (CMAX + 4) * 4 + CMAX * 2 + 4 * NW * 8 + 4 * NW * 4 + 16 + 6 * NW * 4 + 64;
+}
+
+template <int T, int CPT, int MODE>
+__global__ void __launch_bounds__(T)
+fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+           long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+           float* __restrict__ md)
+{
+    constexpr int NW = T / 64, CMAX = T * CPT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* key = (unsigned long long*)smem;                 // [CMAX] cell arg-max keys
+    float* cx = (float*)(key + CMAX);                                    // [CMAX] xyz of each cell's arg-max
+    float* cy = cx + CMAX;
+    float* cz = cy + CMAX;
+    int* cstart = (int*)(cz + CMAX);                                     // [CMAX+1] first sorted row of a cell
+    unsigned short* queue = (unsigned short*)(cstart + CMAX + 4);        // [CMAX] active cells of the round
+    unsigned long long* pkey = (unsigned long long*)(queue + CMAX);      // [2][2*NW] wave partials
+    int* pcell = (int*)(pkey + 4 * NW);                                  // [2][2*NW]
+    int* qcount = pcell + 4 * NW;                                        // [2] (+2 pad)
+    float* red = (float*)(qcount + 4);                                   // [6*NW] / scan scratch
+    int* cursor = (int*)key;                                             // prologue alias
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = offsets[b];
+    const int M = (int)(offsets[b + 1] - base);
+    const int kn = K < M ? K : (M > 0 ? M : 0);
+    long long* irow = idx + (size_t)b * K;
+    float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
+    for (int k = kn + tid; k < K; k += T) {                              // pytorch3d padding
+        irow[k] = -1;
+        if (orow) { orow[3 * k] = 0.f; orow[3 * k + 1] = 0.f; orow[3 * k + 2] = 0.f; }
+    }
+    if (kn == 0) return;
+    const float* P = xyz + 3 * base;
+    float4* S = pts4 + base;
+    float* D = md + base;
+
+    // ---- prologue 1: bounding box -------------------------------------------------------------
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int p = tid; p < M; p += T) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = P[3 * p + c];
+            lo[c] = fminf(lo[c], v);
+            hi[c] = fmaxf(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lo[c] = wave_min_f32(lo[c]); hi[c] = wave_max_f32(hi[c]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { red[wave * 6 + c] = lo[c]; red[wave * 6 + 3 + c] = hi[c]; }
+    }
+    for (int c = tid; c < CMAX + 1; c += T) cstart[c] = 0;
+    for (int c = tid; c < CMAX; c += T) cursor[c] = 0;
+    if (tid < 4) qcount[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = red[c]; hi[c] = red[3 + c];
+        for (int w = 1; w < NW; ++w) { lo[c] = fminf(lo[c], red[w * 6 + c]); hi[c] = fmaxf(hi[c], red[w * 6 + 3 + c]); }
+    }
+    // grid: roughly cubic cells, at most CMAX of them, about PCP_BUCKET_TARGET_PTS points each
+    int g[3] = {1, 1, 1};
+    float inv_h[3] = {0.f, 0.f, 0.f};
+    {
+        float e[3];
+        float emax = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { e[c] = hi[c] - lo[c]; if (!(e[c] > 0.f) || !(e[c] < INFINITY)) e[c] = 0.f; emax = fmaxf(emax, e[c]); }
+        int target = M / PCP_BUCKET_TARGET_PTS;
+        target = min(CMAX, max(1, target));
+        if (emax > 0.f && target > 1) {
+            float vol = 1.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vol *= fmaxf(e[c], emax * 1e-3f);
+            float h = cbrtf(vol / (float)target);
+            for (int it = 0; it < 200; ++it) {
+                long long prod = 1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float gc = ceilf(e[c] / h);
+                    g[c] = (int)fminf(fmaxf(gc, 1.f), (float)CMAX);
+                    prod *= g[c];
+                }
+                if (prod <= CMAX) break;
+                h *= 1.04f;
+                if (it == 199) { g[0] = g[1] = g[2] = 1; }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) inv_h[c] = e[c] > 0.f ? (float)g[c] / e[c] : 0.f;
+        }
+    }
+    const int C = g[0] * g[1] * g[2];
+
+    // ---- prologue 2: histogram, scan, scatter (LDS counting sort) ---------------------------------
+    for (int p = tid; p < M; p += T) {
+        const int cell = (grid_cell(P[3 * p], lo[0], inv_h[0], g[0]) * g[1] +
+                          grid_cell(P[3 * p + 1], lo[1], inv_h[1], g[1])) * g[2] +
+                         grid_cell(P[3 * p + 2], lo[2], inv_h[2], g[2]);
+        atomicAdd(&cstart[cell], 1);
+    }
+    __syncthreads();
+    {
+        int local[CPT];
+        int sum = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { local[j] = cstart[tid * CPT + j]; sum += local[j]; }
+        __syncthreads();
+        int total;
+        int ex = pcp_block_excl_scan(sum, (int*)red, &total);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) { cstart[tid * CPT + j] = ex; cursor[tid * CPT + j] = ex; ex += local[j]; }
+        if (tid == T - 1) cstart[CMAX] = ex;
+    }
+    __syncthreads();
+    for (int p = tid; p < M; p += T) {
+        const float x = P[3 * p], y = P[3 * p + 1], z = P[3 * p + 2];
+        const int cell = (grid_cell(x, lo[0], inv_h[0], g[0]) * g[1] + grid_cell(y, lo[1], inv_h[1], g[1])) * g[2] +
+                         grid_cell(z, lo[2], inv_h[2], g[2]);
+        const int pos = atomicAdd(&cursor[cell], 1);
+        S[pos] = make_float4(x, y, z, __int_as_float(p));
+        D[pos] = FLT_MAX;
+    }
+    __syncthreads();
+
+    // ---- prologue 3: owners take their cells' tight boxes into registers --------------------------
+    float blo[CPT][3], bhi[CPT][3];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int cell = tid + j * T;
+        const int st = cstart[cell], en = cstart[cell + 1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { blo[j][c] = INFINITY; bhi[j][c] = -INFINITY; }
+        for (int i = st; i < en; ++i) {
+            const float4 pt = S[i];
+            blo[j][0] = fminf(blo[j][0], pt.x); bhi[j][0] = fmaxf(bhi[j][0], pt.x);
+            blo[j][1] = fminf(blo[j][1], pt.y); bhi[j][1] = fmaxf(bhi[j][1], pt.y);
+            blo[j][2] = fminf(blo[j][2], pt.z); bhi[j][2] = fmaxf(bhi[j][2], pt.z);
+        }
+        (void)C;
+    }
+    __syncthreads();                                   // cursor (aliases key) no longer needed
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int cell = tid + j * T;
+        key[cell] = cstart[cell + 1] > cstart[cell] ? make_key(FLT_MAX, 0u) : 0ull;
+    }
+    float sx = P[0], sy = P[1], sz = P[2];
+    int last = 0;
+    __syncthreads();
+
+    // ---- rounds -------------------------------------------------------------------------------------
+    for (int k = 0;; ++k) {
+        if (tid == 0) {
+            irow[k] = last;
+            if (orow) { orow[3 * k] = sx; orow[3 * k + 1] = sy; orow[3 * k + 2] = sz; }
+        }
+        if (k + 1 >= kn) break;
+        const int par = k & 1;
+        // phase A: cell tests by the owners
+        unsigned long long ka = 0ull;
+        int ka_cell = 0;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int cell = tid + j * T;
+            const unsigned long long kj = key[cell];
+            const float cmax = __uint_as_float((unsigned)(kj >> 32));
+            const float qx = fminf(fmaxf(sx, blo[j][0]), bhi[j][0]);
+            const float qy = fminf(fmaxf(sy, blo[j][1]), bhi[j][1]);
+            const float qz = fminf(fmaxf(sz, blo[j][2]), bhi[j][2]);
+            const float lb = dist2<MODE>(sx, sy, sz, qx, qy, qz);
+            if (lb < cmax) {
+                const int slot = atomicAdd(&qcount[par], 1);
+                queue[slot] = (unsigned short)cell;
+            } else if (kj > ka) {
+                ka = kj;
+                ka_cell = cell;
+            }
+        }
+        {
+            const unsigned long long wk = wave_umax_key(ka);
+            if (ka == wk) { pkey[par * 2 * NW + wave] = wk; pcell[par * 2 * NW + wave] = ka_cell; }
+        }
+        __syncthreads();
+        // phase B: update the points of the queued cells
+        if (tid == 0) qcount[par ^ 1] = 0;
+        const int nq = qcount[par];
+        unsigned long long wbest = 0ull;
+        int wbest_cell = 0;
+        for (int e = wave; e < nq; e += NW) {
+            const int cell = queue[e];
+            const int st = cstart[cell], cnt = cstart[cell + 1] - st;
+            unsigned long long bk = 0ull;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            for (int i = lane; i < cnt; i += 64) {
+                const float4 pt = S[st + i];
+                float m = D[st + i];
+                const float d = dist2<MODE>(sx, sy, sz, pt.x, pt.y, pt.z);
+                if (d < m) { m = d; D[st + i] = m; }
+                const unsigned long long kk = make_key(m, (unsigned)__float_as_int(pt.w));
+                if (kk > bk) { bk = kk; bx = pt.x; by = pt.y; bz = pt.z; }
+            }
+            const unsigned long long wk = wave_umax_key(bk);
+            if (bk == wk) { key[cell] = wk; cx[cell] = bx; cy[cell] = by; cz[cell] = bz; }
+            if (wk > wbest) { wbest = wk; wbest_cell = cell; }
+        }
+        if (lane == 0) { pkey[par * 2 * NW + NW + wave] = wbest; pcell[par * 2 * NW + NW + wave] = wbest_cell; }
+        __syncthreads();
+        // phase C: arg-max over the 2*NW wave partials
+        {
+            const unsigned long long kk = lane < 2 * NW ? pkey[par * 2 * NW + lane] : 0ull;
+            const int cc = lane < 2 * NW ? pcell[par * 2 * NW + lane] : 0;
+            const unsigned long long wk = wave_umax_key(kk);
+            const unsigned long long hit = __ballot(kk == wk);
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int cell = __builtin_amdgcn_readlane(cc, src);
+            last = wk ? (int)(~(unsigned)wk) : 0;
+            sx = cx[cell]; sy = cy[cell]; sz = cz[cell];
+        }
+    }
+}
+
 // ---- host entry points -------------------------------------------------------------------------
+static int fps_pick_algo(int algo, int64_t max_pts)
+{
+    if (algo != 0) return algo;
+    return max_pts >= 2048 ? 2 : 1;
+}
+
+// workspace: sorted records float4[total] | min_d float[total]
 extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo)
 {
-    (void)B; (void)max_pts; (void)K; (void)algo;
+    (void)B; (void)K; (void)algo; (void)max_pts;
     if (total_pts < 0) total_pts = 0;
-    return pcp_align256((size_t)total_pts * sizeof(float)) + 256;
+    return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
+}
+
+#define PCP_BUCKET_T 512
+#define PCP_BUCKET_CPT 4
+
+template <int MODE>
+static int launch_bucket(const float* xyz, const long long* offsets, int B, int K, long long* idx,
+                         float* out_xyz, float4* pts4, float* md, hipStream_t st)
+{
+    constexpr size_t lds = fps_bucket_lds_bytes<PCP_BUCKET_T, PCP_BUCKET_CPT>();
+    auto kern = fps_bucket<PCP_BUCKET_T, PCP_BUCKET_CPT, MODE>;
+    if (lds > 48 * 1024)
+        PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(PCP_BUCKET_T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md);
+    return pcp_launch_status();
 }
 
 extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
@@ -109,12 +423,15 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
         return PCP_ERR_WORKSPACE;
     if (B == 0 || K == 0) return PCP_OK;
     hipStream_t st = (hipStream_t)stream;
-    float* md = (float*)ws;
+    float4* pts4 = (float4*)ws;
+    float* md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
+    const long long* off = (const long long*)offsets;
+    if (fps_pick_algo(algo, max_pts) == 2)
+        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, K, (long long*)idx, out_xyz, pts4, md, st)
+                              : launch_bucket<1>(xyz, off, B, K, (long long*)idx, out_xyz, pts4, md, st);
     if (dist_mode == 0)
-        hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, (const long long*)offsets, K,
-                           (long long*)idx, out_xyz, md);
+        hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
     else
-        hipLaunchKernelGGL(fps_brute<1>, dim3(B), dim3(1024), 0, st, xyz, (const long long*)offsets, K,
-                           (long long*)idx, out_xyz, md);
+        hipLaunchKernelGGL(fps_brute<1>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
     return pcp_launch_status();
 }

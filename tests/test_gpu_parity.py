@@ -179,7 +179,7 @@ def run_fps(clouds, K, dist_mode=0, algo=0):
     return xyz.cpu().numpy(), idx.cpu().numpy()
 
 
-ALGOS = [1]
+ALGOS = [1, 2]
 
 
 @pytest.mark.parametrize("algo", ALGOS)

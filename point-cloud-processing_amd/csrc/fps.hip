@@ -150,7 +150,17 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int g)
     return min(g - 1, max(0, c));
 }
 
+#ifndef PCP_BUCKET_TARGET_PTS
 #define PCP_BUCKET_TARGET_PTS 16       // aim for about this many points per cell
+#endif
+
+// Diagnostic build only (make stamps): per-phase cycle sums printed by workgroup 0.
+#ifdef PCP_FPS_STAMPS
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+//       // aim for about this many points per cell
 
 template <int T, int CPT>
 constexpr size_t fps_bucket_lds_bytes()
@@ -194,15 +204,26 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     float4* S = pts4 + base;
     float* D = md + base;
 
+#ifdef PCP_FPS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, tp0 = 0, tp1 = 0;
+    unsigned long long sA = 0, sW1 = 0, sB = 0, sW2 = 0, sC = 0, sQ = 0, sPts = 0, sMem = 0, sPass = 0;
+    STAMP(tp0);
+#endif
     // ---- prologue 1: bounding box -------------------------------------------------------------
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int p = tid; p < M; p += T) {
+    constexpr int PU = 8;                               // points in flight per thread in the prologue
+    for (int p0 = tid; p0 < M; p0 += T * PU) {
+        float v[PU][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = P[3 * p + c];
-            lo[c] = fminf(lo[c], v);
-            hi[c] = fmaxf(hi[c], v);
+        for (int u = 0; u < PU; ++u) {
+            const int p = min(p0 + u * T, M - 1);           // clamped duplicates do not change min/max
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = P[3 * p + c];
         }
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], v[u][c]); hi[c] = fmaxf(hi[c], v[u][c]); }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { lo[c] = wave_min_f32(lo[c]); hi[c] = wave_max_f32(hi[c]); }
@@ -253,11 +274,21 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     const int C = g[0] * g[1] * g[2];
 
     // ---- prologue 2: histogram, scan, scatter (LDS counting sort) ---------------------------------
-    for (int p = tid; p < M; p += T) {
-        const int cell = (grid_cell(P[3 * p], lo[0], inv_h[0], g[0]) * g[1] +
-                          grid_cell(P[3 * p + 1], lo[1], inv_h[1], g[1])) * g[2] +
-                         grid_cell(P[3 * p + 2], lo[2], inv_h[2], g[2]);
-        atomicAdd(&cstart[cell], 1);
+    for (int p0 = tid; p0 < M; p0 += T * PU) {
+        float v[PU][3];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int p = min(p0 + u * T, M - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = P[3 * p + c];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int cell = (grid_cell(v[u][0], lo[0], inv_h[0], g[0]) * g[1] +
+                              grid_cell(v[u][1], lo[1], inv_h[1], g[1])) * g[2] +
+                             grid_cell(v[u][2], lo[2], inv_h[2], g[2]);
+            if (p0 + u * T < M) atomicAdd(&cstart[cell], 1);
+        }
     }
     __syncthreads();
     {
@@ -273,29 +304,60 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         if (tid == T - 1) cstart[CMAX] = ex;
     }
     __syncthreads();
-    for (int p = tid; p < M; p += T) {
-        const float x = P[3 * p], y = P[3 * p + 1], z = P[3 * p + 2];
-        const int cell = (grid_cell(x, lo[0], inv_h[0], g[0]) * g[1] + grid_cell(y, lo[1], inv_h[1], g[1])) * g[2] +
-                         grid_cell(z, lo[2], inv_h[2], g[2]);
-        const int pos = atomicAdd(&cursor[cell], 1);
-        S[pos] = make_float4(x, y, z, __int_as_float(p));
-        D[pos] = FLT_MAX;
+    for (int p0 = tid; p0 < M; p0 += T * PU) {
+        float v[PU][3];
+        int pos[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int p = min(p0 + u * T, M - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[u][c] = P[3 * p + c];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int cell = (grid_cell(v[u][0], lo[0], inv_h[0], g[0]) * g[1] +
+                              grid_cell(v[u][1], lo[1], inv_h[1], g[1])) * g[2] +
+                             grid_cell(v[u][2], lo[2], inv_h[2], g[2]);
+            pos[u] = (p0 + u * T < M) ? atomicAdd(&cursor[cell], 1) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+            if (pos[u] >= 0) {
+                S[pos[u]] = make_float4(v[u][0], v[u][1], v[u][2], __int_as_float(p0 + u * T));
+                D[pos[u]] = FLT_MAX;
+            }
     }
     __syncthreads();
 
     // ---- prologue 3: owners take their cells' tight boxes into registers --------------------------
     float blo[CPT][3], bhi[CPT][3];
+    {
+        int st[CPT], cn[CPT], cmaxn = 0;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int cell = tid + j * T;
-        const int st = cstart[cell], en = cstart[cell + 1];
+        for (int j = 0; j < CPT; ++j) {
+            const int cell = tid + j * T;
+            st[j] = cstart[cell];
+            cn[j] = cstart[cell + 1] - st[j];
+            cmaxn = max(cmaxn, cn[j]);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { blo[j][c] = INFINITY; bhi[j][c] = -INFINITY; }
-        for (int i = st; i < en; ++i) {
-            const float4 pt = S[i];
-            blo[j][0] = fminf(blo[j][0], pt.x); bhi[j][0] = fmaxf(bhi[j][0], pt.x);
-            blo[j][1] = fminf(blo[j][1], pt.y); bhi[j][1] = fmaxf(bhi[j][1], pt.y);
-            blo[j][2] = fminf(blo[j][2], pt.z); bhi[j][2] = fmaxf(bhi[j][2], pt.z);
+            for (int c = 0; c < 3; ++c) { blo[j][c] = INFINITY; bhi[j][c] = -INFINITY; }
+        }
+        for (int i = 0; i < cmaxn; i += 2) {              // CPT x 2 independent loads in flight
+            float4 pt[CPT][2];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)          // unconditional, clamped: loads stay in flight together
+                    pt[j][u] = S[min(st[j] + min(i + u, max(cn[j] - 1, 0)), M - 1)];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (i + u < cn[j]) {
+                        blo[j][0] = fminf(blo[j][0], pt[j][u].x); bhi[j][0] = fmaxf(bhi[j][0], pt[j][u].x);
+                        blo[j][1] = fminf(blo[j][1], pt[j][u].y); bhi[j][1] = fmaxf(bhi[j][1], pt[j][u].y);
+                        blo[j][2] = fminf(blo[j][2], pt[j][u].z); bhi[j][2] = fmaxf(bhi[j][2], pt[j][u].z);
+                    }
         }
         (void)C;
     }
@@ -309,6 +371,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     int last = 0;
     __syncthreads();
 
+    STAMP(tp1);
     // ---- rounds -------------------------------------------------------------------------------------
     for (int k = 0;; ++k) {
         if (tid == 0) {
@@ -317,6 +380,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         }
         if (k + 1 >= kn) break;
         const int par = k & 1;
+        STAMP(t0);
         // phase A: cell tests by the owners
         unsigned long long ka = 0ull;
         int ka_cell = 0;
@@ -341,31 +405,65 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             const unsigned long long wk = wave_umax_key(ka);
             if (ka == wk) { pkey[par * 2 * NW + wave] = wk; pcell[par * 2 * NW + wave] = ka_cell; }
         }
+        STAMP(t1);
         __syncthreads();
+        STAMP(t2);
         // phase B: update the points of the queued cells
         if (tid == 0) qcount[par ^ 1] = 0;
         const int nq = qcount[par];
         unsigned long long wbest = 0ull;
         int wbest_cell = 0;
-        for (int e = wave; e < nq; e += NW) {
-            const int cell = queue[e];
-            const int st = cstart[cell], cnt = cstart[cell + 1] - st;
-            unsigned long long bk = 0ull;
-            float bx = 0.f, by = 0.f, bz = 0.f;
-            for (int i = lane; i < cnt; i += 64) {
-                const float4 pt = S[st + i];
-                float m = D[st + i];
-                const float d = dist2<MODE>(sx, sy, sz, pt.x, pt.y, pt.z);
-                if (d < m) { m = d; D[st + i] = m; }
-                const unsigned long long kk = make_key(m, (unsigned)__float_as_int(pt.w));
-                if (kk > bk) { bk = kk; bx = pt.x; by = pt.y; bz = pt.z; }
+        constexpr int BU = 4;                           // cells in flight per wave
+        for (int e0 = wave; e0 < nq; e0 += NW * BU) {
+            int cell[BU], st[BU], cnt[BU];
+            float4 pt[BU];
+            float m[BU];
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                const int e = e0 + u * NW;
+                const bool ok = e < nq;
+                cell[u] = (int)queue[ok ? e : e0];
+                st[u] = cstart[cell[u]];
+                cnt[u] = ok ? cstart[cell[u] + 1] - st[u] : 0;
             }
-            const unsigned long long wk = wave_umax_key(bk);
-            if (bk == wk) { key[cell] = wk; cx[cell] = bx; cy[cell] = by; cz[cell] = bz; }
-            if (wk > wbest) { wbest = wk; wbest_cell = cell; }
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {                  // unconditional, clamped (no per-load waits)
+                const int r = st[u] + min(lane, max(cstart[cell[u] + 1] - st[u] - 1, 0));
+                pt[u] = S[r];
+                m[u] = D[r];
+            }
+#ifdef PCP_FPS_STAMPS
+            { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; sPass += 1; }
+#endif
+#pragma unroll
+            for (int u = 0; u < BU; ++u) {
+                if (cnt[u] == 0) continue;              // wave-uniform
+                unsigned long long bk = 0ull;
+                float bx = 0.f, by = 0.f, bz = 0.f;
+                if (lane < cnt[u]) {
+                    const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
+                    float mm = m[u];
+                    if (d < mm) { mm = d; D[st[u] + lane] = mm; }
+                    bk = make_key(mm, (unsigned)__float_as_int(pt[u].w));
+                    bx = pt[u].x; by = pt[u].y; bz = pt[u].z;
+                }
+                for (int i = lane + 64; i < cnt[u]; i += 64) {       // cells with more than 64 points
+                    const float4 q = S[st[u] + i];
+                    float mm = D[st[u] + i];
+                    const float d = dist2<MODE>(sx, sy, sz, q.x, q.y, q.z);
+                    if (d < mm) { mm = d; D[st[u] + i] = mm; }
+                    const unsigned long long kk = make_key(mm, (unsigned)__float_as_int(q.w));
+                    if (kk > bk) { bk = kk; bx = q.x; by = q.y; bz = q.z; }
+                }
+                const unsigned long long wk = wave_umax_key(bk);
+                if (bk == wk) { key[cell[u]] = wk; cx[cell[u]] = bx; cy[cell[u]] = by; cz[cell[u]] = bz; }
+                if (wk > wbest) { wbest = wk; wbest_cell = cell[u]; }
+            }
         }
         if (lane == 0) { pkey[par * 2 * NW + NW + wave] = wbest; pcell[par * 2 * NW + NW + wave] = wbest_cell; }
+        STAMP(t3);
         __syncthreads();
+        STAMP(t4);
         // phase C: arg-max over the 2*NW wave partials
         {
             const unsigned long long kk = lane < 2 * NW ? pkey[par * 2 * NW + lane] : 0ull;
@@ -377,7 +475,18 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             last = wk ? (int)(~(unsigned)wk) : 0;
             sx = cx[cell]; sy = cy[cell]; sz = cz[cell];
         }
+#ifdef PCP_FPS_STAMPS
+        STAMP(t5);
+        sA += t1 - t0; sW1 += t2 - t1; sB += t3 - t2; sW2 += t4 - t3; sC += t5 - t4; sQ += nq;
+#endif
     }
+#ifdef PCP_FPS_STAMPS
+    if (b == 0 && lane == 0 && (wave == 0 || wave == NW - 1))
+        printf("[stamps] wave %d M=%d C=%d g=%dx%dx%d rounds=%d prologue=%llu | per round: A=%llu bar1=%llu B=%llu bar2=%llu C=%llu cycles, queue=%.1f cells, passes/round=%.2f memwait/pass=%llu\n",
+               wave, M, C, g[0], g[1], g[2], kn - 1, tp1 - tp0, sA / (kn - 1), sW1 / (kn - 1), sB / (kn - 1),
+               sW2 / (kn - 1), sC / (kn - 1), (double)sQ / (kn - 1), (double)sPass / (kn - 1), sMem / (sPass ? sPass : 1));
+    (void)sPts;
+#endif
 }
 
 // ---- host entry points -------------------------------------------------------------------------

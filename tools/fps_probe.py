@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Developer probe: time pcp_fps_batched alone on stage-1 output of N synthetic frames.
+   python tools/fps_probe.py --frames 300 --K 1024 2 --algo 2 [--reps 5]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "point-cloud-processing_amd"))
+import numpy as np, torch
+from pcp import _ffi, ops, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=300)
+ap.add_argument("--K", type=int, nargs="+", default=[1024])
+ap.add_argument("--algo", type=int, default=2)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--H", type=int, default=480); ap.add_argument("--W", type=int, default=640)
+ap.add_argument("--f", type=float, default=605.0)
+a = ap.parse_args()
+dev = "cuda"
+intr = synth.intrinsics(a.H, a.W, a.f)
+p = _ffi.make_params(intr, intr, apply_crop=True)
+d, c = synth.episode(a.frames, 0, a.H, a.W)
+s1 = ops.Stage1(a.frames, a.H, a.W, dev, want=("xyz32",))
+out, off = s1.run(torch.from_numpy(d).to(dev), torch.from_numpy(c).to(dev), p)
+torch.cuda.synchronize()
+total = int(off[-1]); xyz = out["xyz32"][:total].clone()
+print("frames", a.frames, "total pts", total, "mean", total / a.frames)
+for K in a.K:
+    plan = ops.Fps(a.frames, total, a.H * a.W, K, dev, 0, a.algo)
+    plan.run(xyz, off); torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); plan.run(xyz, off); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(f"K={K} algo={a.algo}: min {min(ts):.3f} ms  median {sorted(ts)[len(ts)//2]:.3f} ms")

@@ -88,22 +88,7 @@ fps_brute(const float* __restrict__ xyz, const long long* __restrict__ offsets, 
     }
 }
 
-// ---- exact bucket-pruned FPS ------------------------------------------------------------------
-// Same picks as the brute-force scan, far fewer distance evaluations (≈20-35·M instead of
-// (K-1)·M on the benchmark frames).  One workgroup owns one cloud:
-//   prologue  bounding box → uniform grid of ≤ T*CPT cells → LDS counting sort of the points
-//             into {x,y,z,orig_idx} records grouped by cell (+ one min_d float per point);
-//             thread t owns cells t, t+T, … and keeps their tight boxes in registers.
-//   round     A  every owner tests its cells: lb = dist2(s, clamp(s, box)).  The same rounded
-//                operation sequence as the point distance and monotone rounding give
-//                lb <= dist2(s,p) for every p in the box, so a cell with lb >= cell_max cannot
-//                change and is skipped; the others are queued.  The arg-max over the owner's
-//                skipped cells is reduced per wave.
-//             B  waves drain the queue: one cell = ≤64 points per step, min_d updated in
-//                place, new (cell_max, lowest index, xyz) written to LDS.
-//             C  arg-max over the 2*NW wave partials gives the next sample and its xyz
-//                without touching global memory.
-// Two workgroup barriers and one global-memory round trip per round.
+// ---- wave primitives ---------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v)
 {
@@ -122,12 +107,23 @@ __device__ __forceinline__ unsigned wave_umax_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// wave-uniform maximum of one u64 key per lane
-__device__ __forceinline__ unsigned long long wave_umax_key(unsigned long long k)
+// Wave arg-max of one u64 key per lane.  Returns the wave-uniform maximum key and, in *src,
+// the (uniform) lane that holds it.  Keys of real points are unique (they embed the index),
+// so the second reduction over the low word only runs when two lanes tie on the value.
+__device__ __forceinline__ unsigned long long wave_argmax_key(unsigned long long k, int* src)
 {
     const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
     const unsigned m = wave_umax_u32(hi);
-    const unsigned l = wave_umax_u32(hi == m ? lo : 0u);
+    unsigned long long hit = __ballot(hi == m);
+    unsigned l;
+    if (__popcll(hit) == 1) {                              // wave-uniform branch, the common case
+        *src = __ffsll((long long)hit) - 1;
+        l = (unsigned)__builtin_amdgcn_readlane((int)lo, *src);
+    } else {
+        l = wave_umax_u32(hi == m ? lo : 0u);
+        hit = __ballot(hi == m && lo == l);
+        *src = __ffsll((long long)hit) - 1;
+    }
     return ((unsigned long long)m << 32) | l;
 }
 
@@ -143,16 +139,10 @@ __device__ __forceinline__ float wave_max_f32(float v)
     for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
     return v;
 }
-
-__device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int g)
+__device__ __forceinline__ float rl(float v, int lane)
 {
-    int c = (int)((v - lo) * inv_h);
-    return min(g - 1, max(0, c));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
-
-#ifndef PCP_BUCKET_TARGET_PTS
-#define PCP_BUCKET_TARGET_PTS 16       // aim for about this many points per cell
-#endif
 
 // Diagnostic build only (make stamps): per-phase cycle sums printed by workgroup 0.
 #ifdef PCP_FPS_STAMPS
@@ -160,36 +150,73 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int g)
 #else
 #define STAMP(var) do { } while (0)
 #endif
-//       // aim for about this many points per cell
 
-template <int T, int CPT>
-constexpr size_t fps_bucket_lds_bytes()
+// ---- exact bucket-pruned FPS ------------------------------------------------------------------
+// Same picks as the brute-force scan with ≈40·M instead of (K-1)·M distance evaluations on
+// the benchmark frames.  One workgroup owns one cloud.
+//
+//   prologue  bounding box → 4096-cell Morton grid → LDS counting sort of the points into
+//             {x,y,z,orig_idx} records (+ one min_d float per point) → BUCKETS of BS consecutive
+//             sorted rows (BS = 64 when the cloud has ≤ 64·T·CPL points).  Bucket j belongs to
+//             wave j % NW, lane (j / NW) % 64, slot j / (64·NW); the owning lane keeps the
+//             bucket's tight box, its arg-max key and that point's xyz in registers.
+//   round     every lane tests its buckets: lb = dist2(s, clamp(s, box)).  lb is computed with
+//             the same rounded operation sequence as a point distance, and rounding is
+//             monotone, so lb <= dist2(s,p) for every p in the box: a bucket with
+//             lb >= bucket_max cannot change and is skipped.  A ballot gives the wave its own
+//             active buckets; it streams them four at a time (one coalesced 1 KB + 256 B load
+//             per bucket), updates min_d in place and hands the new arg-max back to the owning
+//             lane with readlane — no queue, no LDS atomics.  One wave arg-max over the lanes'
+//             keys, one LDS partial per wave, ONE workgroup barrier, and every wave reduces the
+//             NW partials to the next sample (xyz included, so nothing global is on the
+//             critical path).
+#define PCP_FPS_CELL_BITS 12
+#define PCP_FPS_NCELL (1 << PCP_FPS_CELL_BITS)
+
+struct MortonPlan {          // cell id = deposit of each axis' quantised coordinate into its id-bit mask
+    unsigned mask[3];
+    int qmax[3];
+    float scale[3];
+    float lo[3];
+};
+
+__device__ __forceinline__ int morton_cell(const MortonPlan& mp, float x, float y, float z)
 {
-    constexpr size_t CMAX = (size_t)T * CPT, NW = T / 64;
-    return CMAX * 8 + CMAX * 12 + (CMAX + 4) * 4 + CMAX * 2 + 4 * NW * 8 + 4 * NW * 4 + 16 + 6 * NW * 4 + 64;
+    const float v[3] = {x, y, z};
+    unsigned id = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsigned q = (unsigned)min(mp.qmax[c], max(0, (int)((v[c] - mp.lo[c]) * mp.scale[c])));
+        for (unsigned m = mp.mask[c]; m; m &= m - 1) {      // wave-uniform trip count
+            id |= (q & 1u) ? (m & (0u - m)) : 0u;
+            q >>= 1;
+        }
+    }
+    return (int)id;
 }
 
-template <int T, int CPT, int MODE>
+template <int T>
+constexpr size_t fps_bucket_lds_bytes()
+{
+    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + 64;
+}
+
+template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T)
 fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
            long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
            float* __restrict__ md)
 {
-    constexpr int NW = T / 64, CMAX = T * CPT;
+    constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
+    static_assert(NCELL % T == 0, "cells per thread must be integral");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long* key = (unsigned long long*)smem;                 // [CMAX] cell arg-max keys
-    float* cx = (float*)(key + CMAX);                                    // [CMAX] xyz of each cell's arg-max
-    float* cy = cx + CMAX;
-    float* cz = cy + CMAX;
-    int* cstart = (int*)(cz + CMAX);                                     // [CMAX+1] first sorted row of a cell
-    unsigned short* queue = (unsigned short*)(cstart + CMAX + 4);        // [CMAX] active cells of the round
-    unsigned long long* pkey = (unsigned long long*)(queue + CMAX);      // [2][2*NW] wave partials
-    int* pcell = (int*)(pkey + 4 * NW);                                  // [2][2*NW]
-    int* qcount = pcell + 4 * NW;                                        // [2] (+2 pad)
-    float* red = (float*)(qcount + 4);                                   // [6*NW] / scan scratch
-    int* cursor = (int*)key;                                             // prologue alias
+    int* cellcnt = (int*)smem;                                           // [NCELL] histogram / cursors
+    float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
+    unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
+    float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
 
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long base = offsets[b];
     const int M = (int)(offsets[b + 1] - base);
     const int kn = K < M ? K : (M > 0 ? M : 0);
@@ -205,13 +232,13 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     float* D = md + base;
 
 #ifdef PCP_FPS_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, tp0 = 0, tp1 = 0;
-    unsigned long long sA = 0, sW1 = 0, sB = 0, sW2 = 0, sC = 0, sQ = 0, sPts = 0, sMem = 0, sPass = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tp0 = 0, tp1 = 0;
+    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0;
     STAMP(tp0);
 #endif
     // ---- prologue 1: bounding box -------------------------------------------------------------
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     constexpr int PU = 8;                               // points in flight per thread in the prologue
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int p0 = tid; p0 < M; p0 += T * PU) {
         float v[PU][3];
 #pragma unroll
@@ -231,49 +258,42 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #pragma unroll
         for (int c = 0; c < 3; ++c) { red[wave * 6 + c] = lo[c]; red[wave * 6 + 3 + c] = hi[c]; }
     }
-    for (int c = tid; c < CMAX + 1; c += T) cstart[c] = 0;
-    for (int c = tid; c < CMAX; c += T) cursor[c] = 0;
-    if (tid < 4) qcount[tid] = 0;
+    for (int c = tid; c < NCELL; c += T) cellcnt[c] = 0;
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         lo[c] = red[c]; hi[c] = red[3 + c];
         for (int w = 1; w < NW; ++w) { lo[c] = fminf(lo[c], red[w * 6 + c]); hi[c] = fmaxf(hi[c], red[w * 6 + 3 + c]); }
     }
-    // grid: roughly cubic cells, at most CMAX of them, about PCP_BUCKET_TARGET_PTS points each
-    int g[3] = {1, 1, 1};
-    float inv_h[3] = {0.f, 0.f, 0.f};
+    // Morton plan: from the top id bit down, give each bit to the axis whose cells are longest;
+    // low id bits are fine coordinate bits, so consecutive ids are spatial neighbours
+    MortonPlan mp;
     {
         float e[3];
-        float emax = 0.f;
+        int bits[3] = {0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { e[c] = hi[c] - lo[c]; if (!(e[c] > 0.f) || !(e[c] < INFINITY)) e[c] = 0.f; emax = fmaxf(emax, e[c]); }
-        int target = M / PCP_BUCKET_TARGET_PTS;
-        target = min(CMAX, max(1, target));
-        if (emax > 0.f && target > 1) {
-            float vol = 1.f;
+        for (int c = 0; c < 3; ++c) {
+            e[c] = hi[c] - lo[c];
+            if (!(e[c] > 0.f) || !(e[c] < INFINITY)) e[c] = 0.f;
+            mp.lo[c] = lo[c];
+            mp.mask[c] = 0u;
+        }
+        for (int t = PCP_FPS_CELL_BITS - 1; t >= 0; --t) {
+            const float l0 = e[0] / (float)(1 << bits[0]), l1 = e[1] / (float)(1 << bits[1]),
+                        l2 = e[2] / (float)(1 << bits[2]);
+            if (!(l0 > 0.f) && !(l1 > 0.f) && !(l2 > 0.f)) break;
+            if (l0 >= l1 && l0 >= l2) { mp.mask[0] |= 1u << t; bits[0]++; }
+            else if (l1 >= l2) { mp.mask[1] |= 1u << t; bits[1]++; }
+            else { mp.mask[2] |= 1u << t; bits[2]++; }
+        }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) vol *= fmaxf(e[c], emax * 1e-3f);
-            float h = cbrtf(vol / (float)target);
-            for (int it = 0; it < 200; ++it) {
-                long long prod = 1;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float gc = ceilf(e[c] / h);
-                    g[c] = (int)fminf(fmaxf(gc, 1.f), (float)CMAX);
-                    prod *= g[c];
-                }
-                if (prod <= CMAX) break;
-                h *= 1.04f;
-                if (it == 199) { g[0] = g[1] = g[2] = 1; }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) inv_h[c] = e[c] > 0.f ? (float)g[c] / e[c] : 0.f;
+        for (int c = 0; c < 3; ++c) {
+            mp.qmax[c] = (1 << bits[c]) - 1;
+            mp.scale[c] = e[c] > 0.f ? (float)(1 << bits[c]) / e[c] : 0.f;
         }
     }
-    const int C = g[0] * g[1] * g[2];
 
-    // ---- prologue 2: histogram, scan, scatter (LDS counting sort) ---------------------------------
+    // ---- prologue 2: histogram, scan, scatter (LDS counting sort by Morton cell) ------------------
     for (int p0 = tid; p0 < M; p0 += T * PU) {
         float v[PU][3];
 #pragma unroll
@@ -284,24 +304,21 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            const int cell = (grid_cell(v[u][0], lo[0], inv_h[0], g[0]) * g[1] +
-                              grid_cell(v[u][1], lo[1], inv_h[1], g[1])) * g[2] +
-                             grid_cell(v[u][2], lo[2], inv_h[2], g[2]);
-            if (p0 + u * T < M) atomicAdd(&cstart[cell], 1);
+            const int cell = morton_cell(mp, v[u][0], v[u][1], v[u][2]);
+            if (p0 + u * T < M) atomicAdd(&cellcnt[cell], 1);
         }
     }
     __syncthreads();
     {
+        constexpr int CPT = NCELL / T;
         int local[CPT];
         int sum = 0;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) { local[j] = cstart[tid * CPT + j]; sum += local[j]; }
-        __syncthreads();
+        for (int j = 0; j < CPT; ++j) { local[j] = cellcnt[tid * CPT + j]; sum += local[j]; }
         int total;
         int ex = pcp_block_excl_scan(sum, (int*)red, &total);
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) { cstart[tid * CPT + j] = ex; cursor[tid * CPT + j] = ex; ex += local[j]; }
-        if (tid == T - 1) cstart[CMAX] = ex;
+        for (int j = 0; j < CPT; ++j) { cellcnt[tid * CPT + j] = ex; ex += local[j]; }
     }
     __syncthreads();
     for (int p0 = tid; p0 < M; p0 += T * PU) {
@@ -315,10 +332,8 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
-            const int cell = (grid_cell(v[u][0], lo[0], inv_h[0], g[0]) * g[1] +
-                              grid_cell(v[u][1], lo[1], inv_h[1], g[1])) * g[2] +
-                             grid_cell(v[u][2], lo[2], inv_h[2], g[2]);
-            pos[u] = (p0 + u * T < M) ? atomicAdd(&cursor[cell], 1) : -1;
+            const int cell = morton_cell(mp, v[u][0], v[u][1], v[u][2]);
+            pos[u] = (p0 + u * T < M) ? atomicAdd(&cellcnt[cell], 1) : -1;
         }
 #pragma unroll
         for (int u = 0; u < PU; ++u)
@@ -329,49 +344,37 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     }
     __syncthreads();
 
-    // ---- prologue 3: owners take their cells' tight boxes into registers --------------------------
-    float blo[CPT][3], bhi[CPT][3];
-    {
-        int st[CPT], cn[CPT], cmaxn = 0;
+    // ---- prologue 3: buckets and their owners ---------------------------------------------------------
+    const int chunks = (M + 64 * NBMAX - 1) / (64 * NBMAX);      // 64-row chunks per bucket (1 up to 64·NBMAX points)
+    const int BS = 64 * chunks;
+    const int NB = (M + BS - 1) / BS;
+    unsigned long long key[CPL];
+    float blo[CPL][3], bhi[CPL][3], ax[CPL], ay[CPL], az[CPL];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int cell = tid + j * T;
-            st[j] = cstart[cell];
-            cn[j] = cstart[cell + 1] - st[j];
-            cmaxn = max(cmaxn, cn[j]);
+    for (int s = 0; s < CPL; ++s) {
+        const int j = (s * 64 + lane) * NW + wave;
+        const int r0 = min(j, NB - 1) * BS;                     // clamped: unowned slots scan a real bucket, then drop it
+        const int rn = min(BS, M - r0);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { blo[j][c] = INFINITY; bhi[j][c] = -INFINITY; }
+        for (int c = 0; c < 3; ++c) { blo[s][c] = INFINITY; bhi[s][c] = -INFINITY; }
+        for (int i = 0; i < rn; i += 8) {
+            float4 pt[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pt[u] = S[r0 + min(i + u, rn - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                blo[s][0] = fminf(blo[s][0], pt[u].x); bhi[s][0] = fmaxf(bhi[s][0], pt[u].x);
+                blo[s][1] = fminf(blo[s][1], pt[u].y); bhi[s][1] = fmaxf(bhi[s][1], pt[u].y);
+                blo[s][2] = fminf(blo[s][2], pt[u].z); bhi[s][2] = fmaxf(bhi[s][2], pt[u].z);
+            }
         }
-        for (int i = 0; i < cmaxn; i += 2) {              // CPT x 2 independent loads in flight
-            float4 pt[CPT][2];
-#pragma unroll
-            for (int j = 0; j < CPT; ++j)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)          // unconditional, clamped: loads stay in flight together
-                    pt[j][u] = S[min(st[j] + min(i + u, max(cn[j] - 1, 0)), M - 1)];
-#pragma unroll
-            for (int j = 0; j < CPT; ++j)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (i + u < cn[j]) {
-                        blo[j][0] = fminf(blo[j][0], pt[j][u].x); bhi[j][0] = fmaxf(bhi[j][0], pt[j][u].x);
-                        blo[j][1] = fminf(blo[j][1], pt[j][u].y); bhi[j][1] = fmaxf(bhi[j][1], pt[j][u].y);
-                        blo[j][2] = fminf(blo[j][2], pt[j][u].z); bhi[j][2] = fmaxf(bhi[j][2], pt[j][u].z);
-                    }
-        }
-        (void)C;
-    }
-    __syncthreads();                                   // cursor (aliases key) no longer needed
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-        const int cell = tid + j * T;
-        key[cell] = cstart[cell + 1] > cstart[cell] ? make_key(FLT_MAX, 0u) : 0ull;
+        key[s] = j < NB ? make_key(FLT_MAX, 0u) : 0ull;         // FLT_MAX: active in round 1; 0: never
+        ax[s] = ay[s] = az[s] = 0.f;
     }
     float sx = P[0], sy = P[1], sz = P[2];
     int last = 0;
-    __syncthreads();
-
     STAMP(tp1);
+
     // ---- rounds -------------------------------------------------------------------------------------
     for (int k = 0;; ++k) {
         if (tid == 0) {
@@ -381,111 +384,99 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         if (k + 1 >= kn) break;
         const int par = k & 1;
         STAMP(t0);
-        // phase A: cell tests by the owners
-        unsigned long long ka = 0ull;
-        int ka_cell = 0;
+        // bucket tests by the owning lanes
+        unsigned long long amask[CPL];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int cell = tid + j * T;
-            const unsigned long long kj = key[cell];
-            const float cmax = __uint_as_float((unsigned)(kj >> 32));
-            const float qx = fminf(fmaxf(sx, blo[j][0]), bhi[j][0]);
-            const float qy = fminf(fmaxf(sy, blo[j][1]), bhi[j][1]);
-            const float qz = fminf(fmaxf(sz, blo[j][2]), bhi[j][2]);
-            const float lb = dist2<MODE>(sx, sy, sz, qx, qy, qz);
-            if (lb < cmax) {
-                const int slot = atomicAdd(&qcount[par], 1);
-                queue[slot] = (unsigned short)cell;
-            } else if (kj > ka) {
-                ka = kj;
-                ka_cell = cell;
-            }
-        }
-        {
-            const unsigned long long wk = wave_umax_key(ka);
-            if (ka == wk) { pkey[par * 2 * NW + wave] = wk; pcell[par * 2 * NW + wave] = ka_cell; }
+        for (int s = 0; s < CPL; ++s) {
+            const float cmax = __uint_as_float((unsigned)(key[s] >> 32));
+            const float qx = fminf(fmaxf(sx, blo[s][0]), bhi[s][0]);
+            const float qy = fminf(fmaxf(sy, blo[s][1]), bhi[s][1]);
+            const float qz = fminf(fmaxf(sz, blo[s][2]), bhi[s][2]);
+            amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
         }
         STAMP(t1);
-        __syncthreads();
-        STAMP(t2);
-        // phase B: update the points of the queued cells
-        if (tid == 0) qcount[par ^ 1] = 0;
-        const int nq = qcount[par];
-        unsigned long long wbest = 0ull;
-        int wbest_cell = 0;
-        constexpr int BU = 4;                           // cells in flight per wave
-        for (int e0 = wave; e0 < nq; e0 += NW * BU) {
-            int cell[BU], st[BU], cnt[BU];
-            float4 pt[BU];
-            float m[BU];
+        // the wave streams its own active buckets, four in flight
+        constexpr int BU = 4;
 #pragma unroll
-            for (int u = 0; u < BU; ++u) {
-                const int e = e0 + u * NW;
-                const bool ok = e < nq;
-                cell[u] = (int)queue[ok ? e : e0];
-                st[u] = cstart[cell[u]];
-                cnt[u] = ok ? cstart[cell[u] + 1] - st[u] : 0;
-            }
+        for (int s = 0; s < CPL; ++s) {
+            unsigned long long m = amask[s];
+            while (m) {                                         // wave-uniform
+                int ol[BU], r0[BU], n = 0;
 #pragma unroll
-            for (int u = 0; u < BU; ++u) {                  // unconditional, clamped (no per-load waits)
-                const int r = st[u] + min(lane, max(cstart[cell[u] + 1] - st[u] - 1, 0));
-                pt[u] = S[r];
-                m[u] = D[r];
-            }
+                for (int u = 0; u < BU; ++u) {
+                    if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                    else ol[u] = ol[0];
+                    r0[u] = ((s * 64 + ol[u]) * NW + wave) * BS;
+                }
 #ifdef PCP_FPS_STAMPS
-            { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; sPass += 1; }
+                sPass += 1; sAct += n;
 #endif
+                unsigned long long bk[BU];
+                float bx[BU], by[BU], bz[BU];
 #pragma unroll
-            for (int u = 0; u < BU; ++u) {
-                if (cnt[u] == 0) continue;              // wave-uniform
-                unsigned long long bk = 0ull;
-                float bx = 0.f, by = 0.f, bz = 0.f;
-                if (lane < cnt[u]) {
-                    const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
-                    float mm = m[u];
-                    if (d < mm) { mm = d; D[st[u] + lane] = mm; }
-                    bk = make_key(mm, (unsigned)__float_as_int(pt[u].w));
-                    bx = pt[u].x; by = pt[u].y; bz = pt[u].z;
+                for (int u = 0; u < BU; ++u) bk[u] = 0ull;
+                for (int c = 0; c < chunks; ++c) {
+                    float4 pt[BU];
+                    float mm[BU];
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) {              // unconditional clamped loads: all in flight together
+                        const int r = min(r0[u] + c * 64 + lane, M - 1);
+                        pt[u] = S[r];
+                        mm[u] = D[r];
+                    }
+#pragma unroll
+                    for (int u = 0; u < BU; ++u) {
+                        const int r = r0[u] + c * 64 + lane;
+                        const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
+                        const bool live = u < n && r < M;
+                        if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
+                        const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
+                        if (c == 0 || kk > bk[u]) { bk[u] = kk; bx[u] = pt[u].x; by[u] = pt[u].y; bz[u] = pt[u].z; }
+                    }
                 }
-                for (int i = lane + 64; i < cnt[u]; i += 64) {       // cells with more than 64 points
-                    const float4 q = S[st[u] + i];
-                    float mm = D[st[u] + i];
-                    const float d = dist2<MODE>(sx, sy, sz, q.x, q.y, q.z);
-                    if (d < mm) { mm = d; D[st[u] + i] = mm; }
-                    const unsigned long long kk = make_key(mm, (unsigned)__float_as_int(q.w));
-                    if (kk > bk) { bk = kk; bx = q.x; by = q.y; bz = q.z; }
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    if (u < n) {                                // wave-uniform
+                        int src;
+                        const unsigned long long wk = wave_argmax_key(bk[u], &src);
+                        const float wx = rl(bx[u], src), wy = rl(by[u], src), wz = rl(bz[u], src);
+                        if (lane == ol[u]) { key[s] = wk; ax[s] = wx; ay[s] = wy; az[s] = wz; }
+                    }
                 }
-                const unsigned long long wk = wave_umax_key(bk);
-                if (bk == wk) { key[cell[u]] = wk; cx[cell[u]] = bx; cy[cell[u]] = by; cz[cell[u]] = bz; }
-                if (wk > wbest) { wbest = wk; wbest_cell = cell[u]; }
             }
         }
-        if (lane == 0) { pkey[par * 2 * NW + NW + wave] = wbest; pcell[par * 2 * NW + NW + wave] = wbest_cell; }
+        STAMP(t2);
+        // wave arg-max over the lanes' buckets → one partial per wave
+        {
+            unsigned long long kb = key[0];
+            float cxx = ax[0], cyy = ay[0], czz = az[0];
+#pragma unroll
+            for (int s = 1; s < CPL; ++s)
+                if (key[s] > kb) { kb = key[s]; cxx = ax[s]; cyy = ay[s]; czz = az[s]; }
+            int src;
+            const unsigned long long wk = wave_argmax_key(kb, &src);
+            if (lane == src) { pkey[par * NW + wave] = wk; pxyz[par * NW + wave] = make_float4(cxx, cyy, czz, 0.f); }
+        }
         STAMP(t3);
         __syncthreads();
         STAMP(t4);
-        // phase C: arg-max over the 2*NW wave partials
         {
-            const unsigned long long kk = lane < 2 * NW ? pkey[par * 2 * NW + lane] : 0ull;
-            const int cc = lane < 2 * NW ? pcell[par * 2 * NW + lane] : 0;
-            const unsigned long long wk = wave_umax_key(kk);
-            const unsigned long long hit = __ballot(kk == wk);
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
-            const int cell = __builtin_amdgcn_readlane(cc, src);
+            const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
+            const float4 cc = pxyz[par * NW + (lane < NW ? lane : 0)];
+            int src;
+            const unsigned long long wk = wave_argmax_key(kk, &src);
             last = wk ? (int)(~(unsigned)wk) : 0;
-            sx = cx[cell]; sy = cy[cell]; sz = cz[cell];
+            sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
         }
 #ifdef PCP_FPS_STAMPS
-        STAMP(t5);
-        sA += t1 - t0; sW1 += t2 - t1; sB += t3 - t2; sW2 += t4 - t3; sC += t5 - t4; sQ += nq;
+        { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4; }
 #endif
     }
 #ifdef PCP_FPS_STAMPS
     if (b == 0 && lane == 0 && (wave == 0 || wave == NW - 1))
-        printf("[stamps] wave %d M=%d C=%d g=%dx%dx%d rounds=%d prologue=%llu | per round: A=%llu bar1=%llu B=%llu bar2=%llu C=%llu cycles, queue=%.1f cells, passes/round=%.2f memwait/pass=%llu\n",
-               wave, M, C, g[0], g[1], g[2], kn - 1, tp1 - tp0, sA / (kn - 1), sW1 / (kn - 1), sB / (kn - 1),
-               sW2 / (kn - 1), sC / (kn - 1), (double)sQ / (kn - 1), (double)sPass / (kn - 1), sMem / (sPass ? sPass : 1));
-    (void)sPts;
+        printf("[stamps] wave %d M=%d NB=%d BS=%d bits=%d rounds=%d prologue=%llu | per round: test=%llu stream=%llu reduce=%llu barrier=%llu pick=%llu cycles; passes/round=%.2f buckets/round(this wave)=%.2f\n",
+               wave, M, NB, BS, __popc(mp.mask[0]) * 100 + __popc(mp.mask[1]) * 10 + __popc(mp.mask[2]), kn - 1, tp1 - tp0, sA / (kn - 1), sB / (kn - 1), sR / (kn - 1), sW / (kn - 1),
+               sC / (kn - 1), (double)sPass / (kn - 1), (double)sAct / (kn - 1));
 #endif
 }
 
@@ -504,15 +495,19 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
 }
 
+#ifndef PCP_BUCKET_T
 #define PCP_BUCKET_T 512
-#define PCP_BUCKET_CPT 4
+#endif
+#ifndef PCP_BUCKET_CPL
+#define PCP_BUCKET_CPL 2      // buckets per lane: 64-row buckets up to 64*T*CPL points, larger ones beyond
+#endif
 
 template <int MODE>
 static int launch_bucket(const float* xyz, const long long* offsets, int B, int K, long long* idx,
                          float* out_xyz, float4* pts4, float* md, hipStream_t st)
 {
-    constexpr size_t lds = fps_bucket_lds_bytes<PCP_BUCKET_T, PCP_BUCKET_CPT>();
-    auto kern = fps_bucket<PCP_BUCKET_T, PCP_BUCKET_CPT, MODE>;
+    constexpr size_t lds = fps_bucket_lds_bytes<PCP_BUCKET_T>();
+    auto kern = fps_bucket<PCP_BUCKET_T, PCP_BUCKET_CPL, MODE>;
     if (lds > 48 * 1024)
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B), dim3(PCP_BUCKET_T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md);

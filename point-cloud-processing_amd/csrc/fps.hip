@@ -15,6 +15,7 @@
 // key 0 means "no candidate".
 #include "pcp_internal.h"
 #include <float.h>
+#include <type_traits>
 
 template <int MODE>
 __device__ __forceinline__ float dist2(float sx, float sy, float sz, float x, float y, float z)
@@ -127,6 +128,85 @@ __device__ __forceinline__ unsigned long long wave_argmax_key(unsigned long long
     return ((unsigned long long)m << 32) | l;
 }
 
+// G independent wave maxima at once: the G DPP chains interleave, so the two wait states every
+// DPP read needs after a VALU write are filled with useful work instead of s_nop.
+template <int G>
+__device__ __forceinline__ void wave_umax_u32_x(unsigned (&v)[G])
+{
+#define PCP_DPP_STEP(CTRL, RM)                                              \
+    {                                                                       \
+        unsigned t_[G];                                                     \
+        _Pragma("unroll") for (int u = 0; u < G; ++u) t_[u] = dpp_u32<CTRL, RM>(v[u]); \
+        _Pragma("unroll") for (int u = 0; u < G; ++u) v[u] = max(v[u], t_[u]);         \
+    }
+    PCP_DPP_STEP(0xB1, 0xf)
+    PCP_DPP_STEP(0x4E, 0xf)
+    PCP_DPP_STEP(0x141, 0xf)
+    PCP_DPP_STEP(0x140, 0xf)
+    PCP_DPP_STEP(0x142, 0xA)
+    PCP_DPP_STEP(0x143, 0xC)
+#undef PCP_DPP_STEP
+#pragma unroll
+    for (int u = 0; u < G; ++u) v[u] = (unsigned)__builtin_amdgcn_readlane((int)v[u], 63);
+}
+
+// G wave arg-maxes at once (see wave_argmax_key); every key set must hold at least one non-zero key
+template <int G>
+__device__ __forceinline__ void wave_argmax_key_x(const unsigned long long (&k)[G],
+                                                  unsigned long long (&wk)[G], int (&src)[G])
+{
+    unsigned m[G];
+    unsigned long long hit[G];
+    bool simple = true;
+#pragma unroll
+    for (int u = 0; u < G; ++u) m[u] = (unsigned)(k[u] >> 32);
+    wave_umax_u32_x<G>(m);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        hit[u] = __ballot((unsigned)(k[u] >> 32) == m[u]);
+        simple = simple && __popcll(hit[u]) == 1;
+    }
+    if (simple) {                                          // wave-uniform, the common case
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            src[u] = __ffsll((long long)hit[u]) - 1;
+            wk[u] = ((unsigned long long)m[u] << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k[u], src[u]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < G; ++u) wk[u] = wave_argmax_key(k[u], &src[u]);
+    }
+}
+
+// arg-max over the keys held by lanes 0..N-1 (N = 4, 8 or 16; other lanes must hold 0)
+template <int N>
+__device__ __forceinline__ unsigned long long lowlanes_argmax_key(unsigned long long k, int* src)
+{
+    unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    unsigned m = hi;
+    m = max(m, dpp_u32<0xB1>(m));
+    m = max(m, dpp_u32<0x4E>(m));
+    if (N > 4) m = max(m, dpp_u32<0x141>(m));
+    if (N > 8) m = max(m, dpp_u32<0x140>(m));
+    m = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
+    unsigned long long hit = __ballot(hi == m);
+    unsigned l;
+    if (__popcll(hit) == 1) {
+        *src = __ffsll((long long)hit) - 1;
+        l = (unsigned)__builtin_amdgcn_readlane((int)lo, *src);
+    } else {
+        unsigned t = hi == m ? lo : 0u;
+        t = max(t, dpp_u32<0xB1>(t));
+        t = max(t, dpp_u32<0x4E>(t));
+        if (N > 4) t = max(t, dpp_u32<0x141>(t));
+        if (N > 8) t = max(t, dpp_u32<0x140>(t));
+        l = (unsigned)__builtin_amdgcn_readlane((int)t, 0);
+        hit = __ballot(hi == m && lo == l);
+        *src = __ffsll((long long)hit) - 1;
+    }
+    return ((unsigned long long)m << 32) | l;
+}
+
 __device__ __forceinline__ float wave_min_f32(float v)
 {
 #pragma unroll
@@ -195,18 +275,19 @@ __device__ __forceinline__ int morton_cell(const MortonPlan& mp, float x, float 
     return (int)id;
 }
 
-template <int T>
+template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
-    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + 64;
+    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
 }
 
-template <int T, int CPL, int MODE>
-__global__ void __launch_bounds__(T)
+template <int T, int CPL, bool MULTI, int MODE>
+__global__ void __launch_bounds__(T, 2048 / T)           // two workgroups per CU: every frame of a 300-frame batch is resident
 fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
            long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-           float* __restrict__ md)
+           float* __restrict__ md, int m_lo, int m_hi)
 {
+    // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
     constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
     static_assert(NCELL % T == 0, "cells per thread must be integral");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,11 +295,13 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
     unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
     float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
+    float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long base = offsets[b];
     const int M = (int)(offsets[b + 1] - base);
+    if (M < m_lo || M > m_hi) return;
     const int kn = K < M ? K : (M > 0 ? M : 0);
     long long* irow = idx + (size_t)b * K;
     float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
@@ -233,7 +316,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 
 #ifdef PCP_FPS_STAMPS
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tp0 = 0, tp1 = 0;
-    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0;
+    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0, sMem = 0, sCmp = 0, sRed = 0, tc0 = 0;
     STAMP(tp0);
 #endif
     // ---- prologue 1: bounding box -------------------------------------------------------------
@@ -349,7 +432,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     const int BS = 64 * chunks;
     const int NB = (M + BS - 1) / BS;
     unsigned long long key[CPL];
-    float blo[CPL][3], bhi[CPL][3], ax[CPL], ay[CPL], az[CPL];
+    float blo[CPL][3], bhi[CPL][3];
 #pragma unroll
     for (int s = 0; s < CPL; ++s) {
         const int j = (s * 64 + lane) * NW + wave;
@@ -369,7 +452,6 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             }
         }
         key[s] = j < NB ? make_key(FLT_MAX, 0u) : 0ull;         // FLT_MAX: active in round 1; 0: never
-        ax[s] = ay[s] = az[s] = 0.f;
     }
     float sx = P[0], sy = P[1], sz = P[2];
     int last = 0;
@@ -395,78 +477,96 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
         }
         STAMP(t1);
-        // the wave streams its own active buckets, four in flight
-        constexpr int BU = 4;
+        // The wave streams its own active buckets, up to four in flight; the pass body is
+        // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
+        auto run_pass = [&](auto GC, const int (&ol)[4], unsigned long long& key_s, int s_base) {
+            constexpr int G = decltype(GC)::value;
+            int r0[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) r0[u] = ((s_base + ol[u]) * NW + wave) * BS;
+            unsigned long long bk[G];
+            float4 bp[G];
+            const int nchunks = MULTI ? chunks : 1;
+            for (int c = 0; c < nchunks; ++c) {
+                float4 pt[G];
+                float mm[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {                   // unconditional clamped loads: all in flight together
+                    const int r = min(r0[u] + c * 64 + lane, M - 1);
+                    pt[u] = S[r];
+                    mm[u] = D[r];
+                }
+#ifdef PCP_FPS_STAMPS
+                { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; STAMP(tc0); }
+#endif
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int r = r0[u] + c * 64 + lane;
+                    const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
+                    const bool live = r < M;
+                    if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
+                    const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
+                    if (!MULTI || c == 0 || kk > bk[u]) { bk[u] = kk; bp[u] = pt[u]; }
+                }
+            }
+#ifdef PCP_FPS_STAMPS
+            { unsigned long long tb; STAMP(tb); sCmp += tb - tc0; tc0 = tb; }
+#endif
+            unsigned long long wk[G];
+            int src[G];
+            wave_argmax_key_x<G>(bk, wk, src);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                if (lane == src[u]) bxyz[(s_base + ol[u]) * NW + wave] = bp[u];
+                if (lane == ol[u]) key_s = wk[u];
+            }
+#ifdef PCP_FPS_STAMPS
+            { unsigned long long tb; STAMP(tb); sRed += tb - tc0; }
+#endif
+        };
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             unsigned long long m = amask[s];
             while (m) {                                         // wave-uniform
-                int ol[BU], r0[BU], n = 0;
+                int ol[4], n = 0;
 #pragma unroll
-                for (int u = 0; u < BU; ++u) {
+                for (int u = 0; u < 4; ++u) {                   // a fourth slot left over repeats slot 0: harmless
                     if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
                     else ol[u] = ol[0];
-                    r0[u] = ((s * 64 + ol[u]) * NW + wave) * BS;
                 }
 #ifdef PCP_FPS_STAMPS
                 sPass += 1; sAct += n;
 #endif
-                unsigned long long bk[BU];
-                float bx[BU], by[BU], bz[BU];
-#pragma unroll
-                for (int u = 0; u < BU; ++u) bk[u] = 0ull;
-                for (int c = 0; c < chunks; ++c) {
-                    float4 pt[BU];
-                    float mm[BU];
-#pragma unroll
-                    for (int u = 0; u < BU; ++u) {              // unconditional clamped loads: all in flight together
-                        const int r = min(r0[u] + c * 64 + lane, M - 1);
-                        pt[u] = S[r];
-                        mm[u] = D[r];
-                    }
-#pragma unroll
-                    for (int u = 0; u < BU; ++u) {
-                        const int r = r0[u] + c * 64 + lane;
-                        const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
-                        const bool live = u < n && r < M;
-                        if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
-                        const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
-                        if (c == 0 || kk > bk[u]) { bk[u] = kk; bx[u] = pt[u].x; by[u] = pt[u].y; bz[u] = pt[u].z; }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < BU; ++u) {
-                    if (u < n) {                                // wave-uniform
-                        int src;
-                        const unsigned long long wk = wave_argmax_key(bk[u], &src);
-                        const float wx = rl(bx[u], src), wy = rl(by[u], src), wz = rl(bz[u], src);
-                        if (lane == ol[u]) { key[s] = wk; ax[s] = wx; ay[s] = wy; az[s] = wz; }
-                    }
-                }
+                if (n == 1) run_pass(std::integral_constant<int, 1>{}, ol, key[s], s * 64);
+                else if (n == 2) run_pass(std::integral_constant<int, 2>{}, ol, key[s], s * 64);
+                else run_pass(std::integral_constant<int, 4>{}, ol, key[s], s * 64);
             }
         }
         STAMP(t2);
         // wave arg-max over the lanes' buckets → one partial per wave
         {
             unsigned long long kb = key[0];
-            float cxx = ax[0], cyy = ay[0], czz = az[0];
+            int sb = 0;
 #pragma unroll
             for (int s = 1; s < CPL; ++s)
-                if (key[s] > kb) { kb = key[s]; cxx = ax[s]; cyy = ay[s]; czz = az[s]; }
+                if (key[s] > kb) { kb = key[s]; sb = s; }
             int src;
             const unsigned long long wk = wave_argmax_key(kb, &src);
-            if (lane == src) { pkey[par * NW + wave] = wk; pxyz[par * NW + wave] = make_float4(cxx, cyy, czz, 0.f); }
+            if (lane == src) {
+                pkey[par * NW + wave] = wk;
+                pxyz[par * NW + wave] = bxyz[(sb * 64 + lane) * NW + wave];
+            }
         }
         STAMP(t3);
         __syncthreads();
         STAMP(t4);
         {
             const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
-            const float4 cc = pxyz[par * NW + (lane < NW ? lane : 0)];
             int src;
-            const unsigned long long wk = wave_argmax_key(kk, &src);
+            const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
+            const float4 cc = pxyz[par * NW + src];
             last = wk ? (int)(~(unsigned)wk) : 0;
-            sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
+            sx = cc.x; sy = cc.y; sz = cc.z;
         }
 #ifdef PCP_FPS_STAMPS
         { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4; }
@@ -474,9 +574,9 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     }
 #ifdef PCP_FPS_STAMPS
     if (b == 0 && lane == 0 && (wave == 0 || wave == NW - 1))
-        printf("[stamps] wave %d M=%d NB=%d BS=%d bits=%d rounds=%d prologue=%llu | per round: test=%llu stream=%llu reduce=%llu barrier=%llu pick=%llu cycles; passes/round=%.2f buckets/round(this wave)=%.2f\n",
+        printf("[stamps] wave %d M=%d NB=%d BS=%d bits=%d rounds=%d prologue=%llu | per round: test=%llu stream=%llu reduce=%llu barrier=%llu pick=%llu cycles; passes/round=%.2f buckets/round(this wave)=%.2f | per pass: memwait=%llu compute=%llu argmax=%llu\n",
                wave, M, NB, BS, __popc(mp.mask[0]) * 100 + __popc(mp.mask[1]) * 10 + __popc(mp.mask[2]), kn - 1, tp1 - tp0, sA / (kn - 1), sB / (kn - 1), sR / (kn - 1), sW / (kn - 1),
-               sC / (kn - 1), (double)sPass / (kn - 1), (double)sAct / (kn - 1));
+               sC / (kn - 1), (double)sPass / (kn - 1), (double)sAct / (kn - 1), sMem / (sPass ? sPass : 1), sCmp / (sPass ? sPass : 1), sRed / (sPass ? sPass : 1));
 #endif
 }
 
@@ -495,23 +595,40 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
 }
 
-#ifndef PCP_BUCKET_T
-#define PCP_BUCKET_T 512
-#endif
-#ifndef PCP_BUCKET_CPL
-#define PCP_BUCKET_CPL 2      // buckets per lane: 64-row buckets up to 64*T*CPL points, larger ones beyond
-#endif
-
-template <int MODE>
-static int launch_bucket(const float* xyz, const long long* offsets, int B, int K, long long* idx,
-                         float* out_xyz, float4* pts4, float* md, hipStream_t st)
+// Launch shapes.  "wide": 16 waves, one 64-row bucket per lane, for clouds of up to 65,536 points
+// (the 640x480 workspace-cropped case); "deep": 8 waves, two buckets per lane, buckets of any
+// multiple of 64 rows, for larger clouds.  The host only knows an upper bound on the cloud sizes,
+// so when that bound exceeds 65,536 both shapes are launched and every workgroup keeps or drops
+// its cloud by its actual size (a dropped workgroup exits at once).
+template <int T, int CPL, bool MULTI, int MODE>
+static int launch_bucket_as(const float* xyz, const long long* offsets, int B, int K, long long* idx,
+                            float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, hipStream_t st)
 {
-    constexpr size_t lds = fps_bucket_lds_bytes<PCP_BUCKET_T>();
-    auto kern = fps_bucket<PCP_BUCKET_T, PCP_BUCKET_CPL, MODE>;
+    constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
+    auto kern = fps_bucket<T, CPL, MULTI, MODE>;
     if (lds > 48 * 1024)
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(PCP_BUCKET_T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
     return pcp_launch_status();
+}
+
+#ifndef PCP_FPS_SHAPE
+#define PCP_FPS_SHAPE 0          // 0: wide for small clouds + deep for large; 2: deep only (tuning builds)
+#endif
+#define PCP_FPS_WIDE_MAX (64 * 1024)
+
+template <int MODE>
+static int launch_bucket(const float* xyz, const long long* offsets, int B, int64_t max_pts, int K,
+                         long long* idx, float* out_xyz, float4* pts4, float* md, hipStream_t st)
+{
+    if (PCP_FPS_SHAPE == 2)
+        return launch_bucket_as<512, 2, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
+                                                           PCP_FPS_WIDE_MAX, st);
+    int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
+                                                          PCP_FPS_WIDE_MAX, st);
+    if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
+    return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
+                                                       PCP_FPS_WIDE_MAX + 1, 0x7fffffff, st);
 }
 
 extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
@@ -531,8 +648,8 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
     float* md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
     const long long* off = (const long long*)offsets;
     if (fps_pick_algo(algo, max_pts) == 2)
-        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, K, (long long*)idx, out_xyz, pts4, md, st)
-                              : launch_bucket<1>(xyz, off, B, K, (long long*)idx, out_xyz, pts4, md, st);
+        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, st)
+                              : launch_bucket<1>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, st);
     if (dist_mode == 0)
         hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
     else

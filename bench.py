@@ -30,7 +30,7 @@ BYTES_PER_FRAME = H * W * (4 + 3) + K_FPS * (12 + 12 + 8)      # SURVEY.md §8d:
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(budget_s=12.0, max_frames=64):
+def cpu_baseline(budget_s=12.0, max_frames=600):
     """The C oracle ("port" of the reference's per-frame path) on this box's host cores,
     single thread like the reference's serial loops, on a bounded sample of the same episode."""
     from oracle import cbind

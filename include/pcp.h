@@ -100,6 +100,14 @@ int pcp_backproject_dense(const float* depth, const uint8_t* rgb,
                           double* pts_cam, float* colors, uint8_t* proj_mask, uint8_t* valid,
                           double* pts_base, uint8_t* crop_mask, void* stream);
 
+/*
+ * align_colors on free-standing camera-frame points — the reference function's own signature,
+ * XPC:66-78 (uses p->color, p->T_d2c, p->zc_min, p->zc_clamp only).
+ *   pts (n,3) f64, rgb (Hc,Wc,3) u8 → colors (n,3) f32 (zero where masked), mask (n) u8
+ */
+int pcp_align_colors(const double* pts, int64_t n, const uint8_t* rgb, int Hc, int Wc,
+                     const pcp_params* p, float* colors, uint8_t* mask, void* stream);
+
 size_t pcp_backproject_workspace_bytes(int B, int H, int W);
 
 /*

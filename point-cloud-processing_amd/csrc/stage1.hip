@@ -48,6 +48,30 @@ __device__ __forceinline__ void rigid3(const double* r, int use_fma, double x, d
     }
 }
 
+// align_colors for one camera-frame point, XPC:66-78: project into the colour image, nearest pixel
+// (half-to-even), in-image + z tests, colour lookup.  Returns proj_mask.
+template <bool NEED_COLOR>
+__device__ __forceinline__ int align_math(const DevParams& P, const double* cam,
+                                          const uint8_t* __restrict__ rgb, int Hc, int Wc, float* col)
+{
+    double cf[3];
+    rigid3(P.T, 1, cam[0], cam[1], cam[2], cf);                   // XPC:67-68
+    double zdiv = cf[2] > P.zc_clamp ? cf[2] : P.zc_clamp;        // np.maximum(z, 0.001)
+    if (cf[2] != cf[2]) zdiv = cf[2];                             //   ... which propagates NaN
+    const double uc = ((cf[0] * P.cfx) / zdiv) + P.ccx;           // XPC:70
+    const double vc = ((cf[1] * P.cfy) / zdiv) + P.ccy;           // XPC:71
+    const double ur = rint(uc), vr = rint(vc);                    // half-to-even, XPC:73
+    const bool inside = (ur >= 0.0) && (ur < (double)Wc) && (vr >= 0.0) && (vr < (double)Hc);
+    const int proj = inside && (cf[2] > P.zc_min);                // XPC:74-75
+    col[0] = col[1] = col[2] = 0.0f;
+    if (NEED_COLOR && proj && rgb) {
+        const uint8_t* px = rgb + ((size_t)(long long)vr * Wc + (size_t)(long long)ur) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) col[c] = (float)((double)px[c] / 255.0);   // XPC:77
+    }
+    return proj;
+}
+
 template <bool NEED_COLOR>
 __device__ __forceinline__ void pixel_math(const DevParams& P, float d, int u, int v,
                                            const uint8_t* __restrict__ rgb, int Hc, int Wc,
@@ -57,28 +81,28 @@ __device__ __forceinline__ void pixel_math(const DevParams& P, float d, int u, i
     o.cam[0] = (((double)u - P.dcx) * z) / P.dfx;                 // XPC:62 multiply, then divide
     o.cam[1] = (((double)v - P.dcy) * z) / P.dfy;                 // XPC:63
     o.cam[2] = z;
-    double cf[3];
-    rigid3(P.T, 1, o.cam[0], o.cam[1], o.cam[2], cf);             // XPC:67-68
-    double zdiv = cf[2] > P.zc_clamp ? cf[2] : P.zc_clamp;        // np.maximum(z, 0.001)
-    if (cf[2] != cf[2]) zdiv = cf[2];                             //   ... which propagates NaN
-    const double uc = ((cf[0] * P.cfx) / zdiv) + P.ccx;           // XPC:70
-    const double vc = ((cf[1] * P.cfy) / zdiv) + P.ccy;           // XPC:71
-    const double ur = rint(uc), vr = rint(vc);                    // half-to-even, XPC:73
-    const bool inside = (ur >= 0.0) && (ur < (double)Wc) && (vr >= 0.0) && (vr < (double)Hc);
-    o.proj = inside && (cf[2] > P.zc_min);                        // XPC:74-75
+    o.proj = align_math<NEED_COLOR>(P, o.cam, rgb, Hc, Wc, o.col);
     o.valid = o.proj && (d > P.z_min) && (d < P.z_max);           // XPC:109 (f32 compares)
-    o.col[0] = o.col[1] = o.col[2] = 0.0f;
-    if (NEED_COLOR && o.proj && rgb) {
-        const uint8_t* px = rgb + ((size_t)(long long)vr * Wc + (size_t)(long long)ur) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) o.col[c] = (float)((double)px[c] / 255.0);   // XPC:77
-    }
     rigid3(P.E, P.transform_fma, o.cam[0], o.cam[1], o.cam[2], o.base);          // XPC:119
     const bool in_box = o.base[0] > P.lo[0] && o.base[0] < P.hi[0] &&
                         o.base[1] > P.lo[1] && o.base[1] < P.hi[1] &&
                         o.base[2] > P.lo[2] && o.base[2] < P.hi[2];              // DP3:35-39
     o.inbox = o.valid && in_box;
     o.keep = o.valid && (!P.apply_crop || in_box);
+}
+
+// align_colors on free-standing points (the reference function's own signature, XPC:66)
+__global__ void __launch_bounds__(256)
+k1_align_points(const double* __restrict__ pts, long long n, const uint8_t* __restrict__ rgb, int Hc,
+                int Wc, DevParams P, float* __restrict__ colors, uint8_t* __restrict__ mask)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double cam[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    float col[3];
+    const int proj = align_math<true>(P, cam, rgb, Hc, Wc, col);
+    if (colors) { colors[3 * i] = col[0]; colors[3 * i + 1] = col[1]; colors[3 * i + 2] = col[2]; }
+    if (mask) mask[i] = (uint8_t)proj;
 }
 
 // ---- dense per-pixel outputs -------------------------------------------------------------
@@ -234,6 +258,16 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
 static bool params_ok(const pcp_params* p)
 {
     return p && p->depth.fx != 0.0 && p->depth.fy != 0.0;
+}
+
+extern "C" int pcp_align_colors(const double* pts, int64_t n, const uint8_t* rgb, int Hc, int Wc,
+                                const pcp_params* p, float* colors, uint8_t* mask, void* stream)
+{
+    if (n < 0 || !p || Hc <= 0 || Wc <= 0 || (n > 0 && (!pts || !rgb))) return PCP_ERR_INVALID_ARG;
+    if (n == 0) return PCP_OK;
+    hipLaunchKernelGGL(k1_align_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pts, (long long)n, rgb, Hc, Wc, pcp_to_dev(p), colors, mask);
+    return pcp_launch_status();
 }
 
 extern "C" int pcp_backproject_dense(const float* depth, const uint8_t* rgb, int B, int H, int W,

@@ -8,7 +8,7 @@ _LIB = os.path.normpath(os.path.join(_HERE, "..", "lib", "libpcp_hip.so"))
 
 EXPORTS = (
     "pcp_default_params", "pcp_strerror", "pcp_version", "pcp_device_count",
-    "pcp_backproject_dense", "pcp_backproject_workspace_bytes", "pcp_backproject_align_crop",
+    "pcp_backproject_dense", "pcp_align_colors", "pcp_backproject_workspace_bytes", "pcp_backproject_align_crop",
     "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact",
     "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_gather_rgb", "pcp_pack_dp3",
 )
@@ -59,6 +59,8 @@ def load_library():
     L.pcp_device_count.argtypes = []; L.pcp_device_count.restype = i32
     L.pcp_backproject_dense.argtypes = [vp, vp, i32, i32, i32, i32, i32, pp, vp, vp, vp, vp, vp, vp, vp]
     L.pcp_backproject_dense.restype = i32
+    L.pcp_align_colors.argtypes = [vp, i64, vp, i32, i32, pp, vp, vp, vp]
+    L.pcp_align_colors.restype = i32
     L.pcp_backproject_workspace_bytes.argtypes = [i32, i32, i32]
     L.pcp_backproject_workspace_bytes.restype = sz
     L.pcp_backproject_align_crop.argtypes = [vp, vp, i32, i32, i32, i32, i32, pp, vp, vp, vp, vp, vp,

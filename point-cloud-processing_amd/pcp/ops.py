@@ -57,6 +57,19 @@ def backproject_dense(depth, rgb, params, want=("pts_cam", "colors", "proj_mask"
     return out
 
 
+def align_colors(pts_cam, rgb, color_intr, T_depth_to_color):
+    """XPC:66-78 on free-standing points: (colors (N,3) f32, mask (N,) u8) device tensors."""
+    _require_cuda(pts_cam, rgb)
+    _chk(pts_cam, torch.float64, "pts_cam"); _chk(rgb, torch.uint8, "rgb")
+    n = pts_cam.shape[0]
+    p = _ffi.make_params(color_intr, color_intr, T=T_depth_to_color, apply_crop=False)
+    colors = torch.empty((n, 3), dtype=torch.float32, device=pts_cam.device)
+    mask = torch.empty(n, dtype=torch.uint8, device=pts_cam.device)
+    check(load_library().pcp_align_colors(_ptr(pts_cam), n, _ptr(rgb), rgb.shape[0], rgb.shape[1],
+                                          C.byref(p), _ptr(colors), _ptr(mask), _stream()))
+    return colors, mask
+
+
 class Stage1:
     """Reusable buffers for pcp_backproject_align_crop on (B,H,W) batches."""
 

@@ -1,0 +1,118 @@
+"""GPU (-m gpu): the drop-in Python entry points (same names/CLIs as the reference) against the
+oracle, including the stage-2 CLI on a synthetic point_clouds/global_frame tree and the stage-1
+per-bag script on a synthetic extracted_data tree."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import cbind, numpy_ref as R
+from pcp import ply
+from helpers import load_npz, intr_dict, synth_frame
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PCP = os.path.join(ROOT, "point-cloud-processing_amd", "pcp")
+
+
+def test_deproject_and_align_colors_functions_match_reference_golden():
+    import pcp.extract_point_clouds_one_cam as xpc
+    g = load_npz("stage1_64x96_c40x60.npz")
+    pts = xpc.deproject(g["depth"], intr_dict(g["dintr"]))
+    assert pts.dtype == np.float64
+    np.testing.assert_array_equal(pts, g["pts_cam"])
+    colors, mask = xpc.align_colors(pts, g["rgb"], intr_dict(g["cintr"]), g["T"])
+    assert colors.dtype == np.float32 and mask.dtype == bool
+    np.testing.assert_array_equal(colors, g["colors"])
+    np.testing.assert_array_equal(mask, g["proj_mask"])
+
+
+def test_farthest_point_sampling_function():
+    import pcp.dp3_point_cloud_processing as dp3
+    rng = np.random.default_rng(40)
+    pts = rng.uniform(-0.4, 0.4, (5000, 3))                       # float64 in, like np.asarray(pcd.points)
+    sampled, idx = dp3.farthest_point_sampling(pts, num_points=2500, use_cuda=True)
+    ref_s, ref_i = cbind.fps(pts, 2500, 0)
+    assert sampled.dtype == np.float32 and idx.dtype == np.int64 and sampled.shape == (2500, 3)
+    np.testing.assert_array_equal(idx, ref_i)
+    np.testing.assert_array_equal(sampled, ref_s)
+    with pytest.raises(ValueError):
+        dp3.farthest_point_sampling(np.zeros((0, 3)), 8)
+
+
+def test_process_point_cloud_matches_oracle_incl_padding():
+    import pcp.dp3_point_cloud_processing as dp3
+    rng = np.random.default_rng(41)
+    xyz = rng.uniform(-0.3, 0.8, (30000, 3))
+    rgb = rng.integers(0, 256, (30000, 3)) / 255.0
+    got_xyz, got_rgb = dp3.process_point_cloud(xyz, rgb, verbose=False)
+    ref_xyz, ref_rgb, _ = R.process_point_cloud(xyz, rgb)
+    np.testing.assert_array_equal(got_xyz, ref_xyz)
+    np.testing.assert_array_equal(got_rgb, ref_rgb)
+    # fewer than 2500 points survive → -1 padding → numpy negative index → last cropped colour (DP3:48)
+    got_xyz, got_rgb = dp3.process_point_cloud(xyz[:3000], rgb[:3000], verbose=False)
+    ref_xyz, ref_rgb, ref_idx = R.process_point_cloud(xyz[:3000], rgb[:3000])
+    assert (ref_idx < 0).any()
+    np.testing.assert_array_equal(got_xyz, ref_xyz)
+    np.testing.assert_array_equal(got_rgb, ref_rgb)
+
+
+def _make_bag_tree(root, bag, n_frames, H=60, W=80):
+    """<root>/<bag>/extracted_data/<bag>/camera/{rgb,depth} + intrinsics.json."""
+    from PIL import Image
+    ext = os.path.join(root, bag, "extracted_data", bag)
+    os.makedirs(os.path.join(ext, "camera", "rgb"))
+    os.makedirs(os.path.join(ext, "camera", "depth"))
+    intr = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    json.dump({"color": intr, "depth": intr}, open(os.path.join(ext, "intrinsics.json"), "w"))
+    frames = []
+    for i in range(n_frames):
+        d, c = synth_frame(100 + i, H, W)
+        np.save(os.path.join(ext, "camera", "depth", f"depth_{i:05d}.npy"), d)
+        Image.fromarray(c).save(os.path.join(ext, "camera", "rgb", f"rgb_{i:05d}.png"))
+        frames.append((d, c))
+    return ext, intr, frames
+
+
+def test_stage1_script_then_stage2_cli_end_to_end(tmp_path):
+    root = str(tmp_path / "processed")
+    ext, intr, frames = _make_bag_tree(root, "bag0", 3)
+    pcd_root = os.path.join(root, "bag0", "point_clouds")
+    ext_str = ",".join(str(v) for v in R.BASE_TO_EXT_CAM_S1.reshape(-1))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(PCP, "extract_point_clouds_one_cam.py"), "--bag_path", ext,
+                        "--extracted_data_root", ext, "--output_root", pcd_root, f"--extrinsics={ext_str}"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    po = cbind.make_params(intr, intr, apply_crop=0)
+    for i, (d, c) in enumerate(frames):
+        ref = cbind.backproject_align_crop(d, c, po)
+        cam, col = ply.read_point_cloud(os.path.join(pcd_root, "camera_frame", f"pc_{i:05d}.ply"))
+        glob, col2 = ply.read_point_cloud(os.path.join(pcd_root, "global_frame", f"pc_{i:05d}.ply"))
+        np.testing.assert_array_equal(cam, ref["xyz_cam64"])
+        np.testing.assert_array_equal(glob, ref["xyz64"])
+        np.testing.assert_array_equal(col, R.ply_colour_roundtrip(ref["rgb32"]))
+        np.testing.assert_array_equal(col, col2)
+    # an empty cloud and a second bag without global_frame: both must be skipped, not fatal
+    ply.write_point_cloud(os.path.join(pcd_root, "global_frame", "pc_00099.ply"), np.zeros((0, 3)), np.zeros((0, 3)))
+    os.makedirs(os.path.join(root, "bag1"))
+    r = subprocess.run([sys.executable, os.path.join(PCP, "pipeline_stage2_filter.py"), "--output_root", root],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "global_frame not found for bag1, skipping" in r.stdout
+    assert "Warning: Empty point cloud" in r.stdout and "Stage 2 complete for: bag0" in r.stdout
+    out_dir = os.path.join(root, "bag0", "filtered_point_clouds")
+    assert sorted(os.listdir(out_dir)) == [f"pc_{i:05d}_filtered.ply" for i in range(3)]
+    for i in range(3):
+        glob, col = ply.read_point_cloud(os.path.join(pcd_root, "global_frame", f"pc_{i:05d}.ply"))
+        ref_xyz, ref_rgb, _ = R.process_point_cloud(glob, col)
+        xyz, rgb = ply.read_point_cloud(os.path.join(out_dir, f"pc_{i:05d}_filtered.ply"))
+        assert xyz.shape == (2500, 3)
+        np.testing.assert_array_equal(xyz, ref_xyz.astype(np.float64))
+        np.testing.assert_array_equal(rgb, R.ply_colour_roundtrip(ref_rgb))
+        # the rows chunking_data.py:134-144 would stack for the zarr
+        np.testing.assert_array_equal(np.concatenate([xyz, rgb * 255], 1).astype(np.float32),
+                                      R.dp3_rows(ref_xyz, ref_rgb))

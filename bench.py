@@ -30,6 +30,18 @@ BYTES_PER_FRAME = H * W * (4 + 3) + K_FPS * (12 + 12 + 8)      # SURVEY.md §8d:
 HBM_PEAK_GBS = 8000.0                                          # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def measured_traffic():
+    """HBM-side bytes per FPS launch from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_*_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        t = json.load(fh)
+    return t.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def cpu_baseline(budget_s=12.0, max_frames=600):
     """The C oracle ("port" of the reference's per-frame path) on this box's host cores,
     single thread like the reference's serial loops, on a bounded sample of the same episode."""
@@ -142,7 +154,8 @@ def main():
                        "frames_per_step_per_gpu": B, "K": K_FPS, "mean_points_after_crop": m_mean,
                        "fps_algo": args.algo, "dist_mode": "nofma"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
+                         "traffic_source": measured_traffic()[1],
                          "kernel": "fps (pcp_fps_batched launches)", "kernel_ms_per_launch": fps_ms,
                          "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME},
         }

@@ -295,7 +295,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
     unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
     float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
-    float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max
+    float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max (written by its wave only)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,13 +477,30 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
         }
         STAMP(t1);
+        // Running wave candidate (all wave-uniform): arg-max over the buckets this round leaves
+        // untouched — reduced while the first loads are in flight — then raised by every bucket the
+        // wave updates.  cand_j is the candidate's bucket: its xyz sits in bxyz[cand_j].
+        unsigned long long cand = 0ull;
+        int cand_j = 0;
+        auto idle_argmax = [&]() {
+            unsigned long long kb = 0ull;
+            int sb = 0;
+#pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                const bool act = (amask[s] >> lane) & 1ull;
+                if (!act && key[s] > kb) { kb = key[s]; sb = s; }
+            }
+            int src;
+            cand = wave_argmax_key(kb, &src);
+            cand_j = ((__builtin_amdgcn_readlane(sb, src) * 64 + src) * NW + wave);
+        };
         // The wave streams its own active buckets, up to four in flight; the pass body is
         // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
-        auto run_pass = [&](auto GC, const int (&ol)[4], unsigned long long& key_s, int s_base) {
+        auto run_pass = [&](auto GC, const int (&ol)[4], unsigned long long& key_s, int s_idx, bool first) {
             constexpr int G = decltype(GC)::value;
             int r0[G];
 #pragma unroll
-            for (int u = 0; u < G; ++u) r0[u] = ((s_base + ol[u]) * NW + wave) * BS;
+            for (int u = 0; u < G; ++u) r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS;
             unsigned long long bk[G];
             float4 bp[G];
             const int nchunks = MULTI ? chunks : 1;
@@ -496,6 +513,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
                     pt[u] = S[r];
                     mm[u] = D[r];
                 }
+                if (first && c == 0) idle_argmax();             // VALU work under the memory latency
 #ifdef PCP_FPS_STAMPS
                 { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; STAMP(tc0); }
 #endif
@@ -517,13 +535,16 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             wave_argmax_key_x<G>(bk, wk, src);
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                if (lane == src[u]) bxyz[(s_base + ol[u]) * NW + wave] = bp[u];
+                const int j = (s_idx * 64 + ol[u]) * NW + wave;
+                if (lane == src[u]) bxyz[j] = bp[u];
                 if (lane == ol[u]) key_s = wk[u];
+                if (wk[u] > cand) { cand = wk[u]; cand_j = j; }          // scalar
             }
 #ifdef PCP_FPS_STAMPS
             { unsigned long long tb; STAMP(tb); sRed += tb - tc0; }
 #endif
         };
+        bool first = true;
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             unsigned long long m = amask[s];
@@ -537,26 +558,16 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #ifdef PCP_FPS_STAMPS
                 sPass += 1; sAct += n;
 #endif
-                if (n == 1) run_pass(std::integral_constant<int, 1>{}, ol, key[s], s * 64);
-                else if (n == 2) run_pass(std::integral_constant<int, 2>{}, ol, key[s], s * 64);
-                else run_pass(std::integral_constant<int, 4>{}, ol, key[s], s * 64);
+                if (n == 1) run_pass(std::integral_constant<int, 1>{}, ol, key[s], s, first);
+                else if (n == 2) run_pass(std::integral_constant<int, 2>{}, ol, key[s], s, first);
+                else run_pass(std::integral_constant<int, 4>{}, ol, key[s], s, first);
+                first = false;
             }
         }
+        if (first) idle_argmax();                               // nothing to stream this round
         STAMP(t2);
-        // wave arg-max over the lanes' buckets → one partial per wave
-        {
-            unsigned long long kb = key[0];
-            int sb = 0;
-#pragma unroll
-            for (int s = 1; s < CPL; ++s)
-                if (key[s] > kb) { kb = key[s]; sb = s; }
-            int src;
-            const unsigned long long wk = wave_argmax_key(kb, &src);
-            if (lane == src) {
-                pkey[par * NW + wave] = wk;
-                pxyz[par * NW + wave] = bxyz[(sb * 64 + lane) * NW + wave];
-            }
-        }
+        // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
+        if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
         STAMP(t3);
         __syncthreads();
         STAMP(t4);

@@ -275,49 +275,18 @@ __device__ __forceinline__ int morton_cell(const MortonPlan& mp, float x, float 
     return (int)id;
 }
 
-template <int T, int CPL>
-constexpr size_t fps_bucket_lds_bytes()
+// Prologue shared by the bucket kernels: bounding box → 4096-cell Morton grid → LDS counting sort of
+// the cloud's points into S = {x,y,z,bits(orig_idx)} records, D = FLT_MAX.  Ends with a barrier.
+template <int T>
+__device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int M, float4* __restrict__ S,
+                                                float* __restrict__ D, int* cellcnt, float* red, int tid,
+                                                int lane, int wave)
 {
-    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
-}
-
-template <int T, int CPL, bool MULTI, int MODE>
-__global__ void __launch_bounds__(T, 2048 / T)           // two workgroups per CU: every frame of a 300-frame batch is resident
-fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
-           long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-           float* __restrict__ md, int m_lo, int m_hi)
-{
-    // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
-    constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
+    constexpr int NW = T / 64, NCELL = PCP_FPS_NCELL;
     static_assert(NCELL % T == 0, "cells per thread must be integral");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* cellcnt = (int*)smem;                                           // [NCELL] histogram / cursors
-    float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
-    unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
-    float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
-    float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max (written by its wave only)
-
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long base = offsets[b];
-    const int M = (int)(offsets[b + 1] - base);
-    if (M < m_lo || M > m_hi) return;
-    const int kn = K < M ? K : (M > 0 ? M : 0);
-    long long* irow = idx + (size_t)b * K;
-    float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
-    for (int k = kn + tid; k < K; k += T) {                              // pytorch3d padding
-        irow[k] = -1;
-        if (orow) { orow[3 * k] = 0.f; orow[3 * k + 1] = 0.f; orow[3 * k + 2] = 0.f; }
-    }
-    if (kn == 0) return;
-    const float* P = xyz + 3 * base;
-    float4* S = pts4 + base;
-    float* D = md + base;
-
 #ifdef PCP_FPS_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tp0 = 0, tp1 = 0;
-    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0, sMem = 0, sCmp = 0, sRed = 0, tc0 = 0;
-    STAMP(tp0);
+    unsigned long long q0, q1, q2, q3, q4;
+    STAMP(q0);
 #endif
     // ---- prologue 1: bounding box -------------------------------------------------------------
     constexpr int PU = 8;                               // points in flight per thread in the prologue
@@ -376,6 +345,9 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         }
     }
 
+#ifdef PCP_FPS_STAMPS
+    STAMP(q1);
+#endif
     // ---- prologue 2: histogram, scan, scatter (LDS counting sort by Morton cell) ------------------
     for (int p0 = tid; p0 < M; p0 += T * PU) {
         float v[PU][3];
@@ -404,6 +376,10 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         for (int j = 0; j < CPT; ++j) { cellcnt[tid * CPT + j] = ex; ex += local[j]; }
     }
     __syncthreads();
+#ifdef PCP_FPS_STAMPS
+    STAMP(q2);
+#endif
+    for (int p = tid; p < M; p += T) D[p] = FLT_MAX;            // coalesced fill instead of a scattered one
     for (int p0 = tid; p0 < M; p0 += T * PU) {
         float v[PU][3];
         int pos[PU];
@@ -422,10 +398,61 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         for (int u = 0; u < PU; ++u)
             if (pos[u] >= 0) {
                 S[pos[u]] = make_float4(v[u][0], v[u][1], v[u][2], __int_as_float(p0 + u * T));
-                D[pos[u]] = FLT_MAX;
             }
     }
     __syncthreads();
+#ifdef PCP_FPS_STAMPS
+    STAMP(q3);
+    if (blockIdx.x == 0 && tid == 0)
+        printf("[stamps] prologue: bbox=%llu hist+scan=%llu scatter=%llu cycles\n", q1 - q0, q2 - q1, q3 - q2);
+    (void)q4;
+#endif
+}
+
+template <int T, int CPL>
+constexpr size_t fps_bucket_lds_bytes()
+{
+    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
+}
+
+template <int T, int CPL, bool MULTI, int MODE>
+__global__ void __launch_bounds__(T, 2048 / T)           // two workgroups per CU: every frame of a 300-frame batch is resident
+fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+           long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+           float* __restrict__ md, int m_lo, int m_hi)
+{
+    // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
+    constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cellcnt = (int*)smem;                                           // [NCELL] histogram / cursors
+    float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
+    unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
+    float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
+    float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max (written by its wave only)
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long base = offsets[b];
+    const int M = (int)(offsets[b + 1] - base);
+    if (M < m_lo || M > m_hi) return;
+    const int kn = K < M ? K : (M > 0 ? M : 0);
+    long long* irow = idx + (size_t)b * K;
+    float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
+    for (int k = kn + tid; k < K; k += T) {                              // pytorch3d padding
+        irow[k] = -1;
+        if (orow) { orow[3 * k] = 0.f; orow[3 * k + 1] = 0.f; orow[3 * k + 2] = 0.f; }
+    }
+    if (kn == 0) return;
+    const float* P = xyz + 3 * base;
+    float4* S = pts4 + base;
+    float* D = md + base;
+
+#ifdef PCP_FPS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tp0 = 0, tp1 = 0;
+    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0, sMem = 0, sCmp = 0, sRed = 0, tc0 = 0;
+    STAMP(tp0);
+#endif
+    fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
 
     // ---- prologue 3: buckets and their owners ---------------------------------------------------------
     const int chunks = (M + 64 * NBMAX - 1) / (64 * NBMAX);      // 64-row chunks per bucket (1 up to 64·NBMAX points)
@@ -586,7 +613,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #ifdef PCP_FPS_STAMPS
     if (b == 0 && lane == 0 && (wave == 0 || wave == NW - 1))
         printf("[stamps] wave %d M=%d NB=%d BS=%d bits=%d rounds=%d prologue=%llu | per round: test=%llu stream=%llu reduce=%llu barrier=%llu pick=%llu cycles; passes/round=%.2f buckets/round(this wave)=%.2f | per pass: memwait=%llu compute=%llu argmax=%llu\n",
-               wave, M, NB, BS, __popc(mp.mask[0]) * 100 + __popc(mp.mask[1]) * 10 + __popc(mp.mask[2]), kn - 1, tp1 - tp0, sA / (kn - 1), sB / (kn - 1), sR / (kn - 1), sW / (kn - 1),
+               wave, M, NB, BS, 0, kn - 1, tp1 - tp0, sA / (kn - 1), sB / (kn - 1), sR / (kn - 1), sW / (kn - 1),
                sC / (kn - 1), (double)sPass / (kn - 1), (double)sAct / (kn - 1), sMem / (sPass ? sPass : 1), sCmp / (sPass ? sPass : 1), sRed / (sPass ? sPass : 1));
 #endif
 }

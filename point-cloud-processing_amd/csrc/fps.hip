@@ -417,6 +417,7 @@ constexpr size_t fps_bucket_lds_bytes()
 
 template <int T, int CPL, bool MULTI, int MODE>
 __global__ void __launch_bounds__(T, 2048 / T)           // two workgroups per CU: every frame of a 300-frame batch is resident
+__attribute__((amdgpu_num_sgpr(80)))                     // 8 waves/SIMD also need <= 80 SGPRs per wave (800 per SIMD, allocated 16 + 16k)
 fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
            long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
            float* __restrict__ md, int m_lo, int m_hi)
@@ -455,7 +456,8 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
 
     // ---- prologue 3: buckets and their owners ---------------------------------------------------------
-    const int chunks = (M + 64 * NBMAX - 1) / (64 * NBMAX);      // 64-row chunks per bucket (1 up to 64·NBMAX points)
+    // 64-row chunks per bucket; the single-chunk shape is only launched for clouds of <= 64·NBMAX points
+    const int chunks = MULTI ? (M + 64 * NBMAX - 1) / (64 * NBMAX) : 1;
     const int BS = 64 * chunks;
     const int NB = (M + BS - 1) / BS;
     unsigned long long key[CPL];
@@ -482,6 +484,10 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
     }
     float sx = P[0], sy = P[1], sz = P[2];
     int last = 0;
+    // Wave-uniform arg-max over ALL buckets the wave owns (key, bucket).  Keys only ever decrease, so
+    // while that bucket is not touched it stays the wave's maximum and no reduction is needed.
+    unsigned long long wmax = __builtin_amdgcn_readfirstlane((int)(key[0] >> 32)) ? make_key(FLT_MAX, 0u) : 0ull;
+    int wmax_j = wave;
     STAMP(tp1);
 
     // ---- rounds -------------------------------------------------------------------------------------
@@ -498,18 +504,23 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             const float cmax = __uint_as_float((unsigned)(key[s] >> 32));
-            const float qx = fminf(fmaxf(sx, blo[s][0]), bhi[s][0]);
-            const float qy = fminf(fmaxf(sy, blo[s][1]), bhi[s][1]);
-            const float qz = fminf(fmaxf(sz, blo[s][2]), bhi[s][2]);
+            const float qx = __builtin_amdgcn_fmed3f(sx, blo[s][0], bhi[s][0]);   // clamp(s, box)
+            const float qy = __builtin_amdgcn_fmed3f(sy, blo[s][1], bhi[s][1]);
+            const float qz = __builtin_amdgcn_fmed3f(sz, blo[s][2], bhi[s][2]);
             amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
         }
         STAMP(t1);
         // Running wave candidate (all wave-uniform): arg-max over the buckets this round leaves
         // untouched — reduced while the first loads are in flight — then raised by every bucket the
         // wave updates.  cand_j is the candidate's bucket: its xyz sits in bxyz[cand_j].
-        unsigned long long cand = 0ull;
-        int cand_j = 0;
+        unsigned long long cand = wmax;
+        int cand_j = wmax_j;
+        bool need_idle = false;
+#pragma unroll
+        for (int s = 0; s < CPL; ++s)                           // is the wave's top bucket about to change?
+            if (((wmax_j / NW) >> 6) == s && ((amask[s] >> ((wmax_j / NW) & 63)) & 1ull)) need_idle = true;
         auto idle_argmax = [&]() {
+            if (!need_idle) return;                             // wave-uniform
             unsigned long long kb = 0ull;
             int sb = 0;
 #pragma unroll
@@ -523,8 +534,9 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
         };
         // The wave streams its own active buckets, up to four in flight; the pass body is
         // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
-        auto run_pass = [&](auto GC, const int (&ol)[4], unsigned long long& key_s, int s_idx, bool first) {
+        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], unsigned long long& key_s, int s_idx, bool first) {
             constexpr int G = decltype(GC)::value;
+            constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
             int r0[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS;
@@ -535,12 +547,20 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
                 float4 pt[G];
                 float mm[G];
 #pragma unroll
-                for (int u = 0; u < G; ++u) {                   // unconditional clamped loads: all in flight together
-                    const int r = min(r0[u] + c * 64 + lane, M - 1);
-                    pt[u] = S[r];
-                    mm[u] = D[r];
+                for (int u = 0; u < G; ++u) {                   // unconditional loads: all in flight together
+                    if (FULL) {                                 // scalar base + lane: no per-lane address math
+                        pt[u] = (S + (r0[u] + c * 64))[lane];
+                        mm[u] = (D + (r0[u] + c * 64))[lane];
+                    } else {
+                        const int r = min(r0[u] + c * 64 + lane, M - 1);
+                        pt[u] = S[r];
+                        mm[u] = D[r];
+                    }
                 }
                 if (first && c == 0) idle_argmax();             // VALU work under the memory latency
+#pragma unroll
+                for (int u = 0; u < G; ++u)                     // keep hipcc from sinking a load into the update branch
+                    asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
 #ifdef PCP_FPS_STAMPS
                 { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; STAMP(tc0); }
 #endif
@@ -548,7 +568,7 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
                 for (int u = 0; u < G; ++u) {
                     const int r = r0[u] + c * 64 + lane;
                     const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
-                    const bool live = r < M;
+                    const bool live = FULL || r < M;
                     if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
                     const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
                     if (!MULTI || c == 0 || kk > bk[u]) { bk[u] = kk; bp[u] = pt[u]; }
@@ -585,18 +605,33 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #ifdef PCP_FPS_STAMPS
                 sPass += 1; sAct += n;
 #endif
-                if (n == 1) run_pass(std::integral_constant<int, 1>{}, ol, key[s], s, first);
-                else if (n == 2) run_pass(std::integral_constant<int, 2>{}, ol, key[s], s, first);
-                else run_pass(std::integral_constant<int, 4>{}, ol, key[s], s, first);
+                using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                using I4 = std::integral_constant<int, 4>;
+                // only the cloud's last bucket can be short of rows; it belongs to lane (NB-1)/NW % 64
+                const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || (((NB - 1) / NW) >> 6) != s ||
+                                  !((amask[s] >> (((NB - 1) / NW) & 63)) & 1ull);
+                if (full) {
+                    if (n == 1) run_pass(I1{}, std::true_type{}, ol, key[s], s, first);
+                    else if (n == 2) run_pass(I2{}, std::true_type{}, ol, key[s], s, first);
+                    else run_pass(I4{}, std::true_type{}, ol, key[s], s, first);
+                } else {
+                    run_pass(I4{}, std::false_type{}, ol, key[s], s, first);
+                }
                 first = false;
             }
         }
         if (first) idle_argmax();                               // nothing to stream this round
+        wmax = cand;                                            // = arg-max over all the wave's buckets again
+        wmax_j = cand_j;
         STAMP(t2);
         // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
         if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
         STAMP(t3);
-        __syncthreads();
+        // Workgroup barrier WITHOUT draining global stores: only LDS traffic (the partials) has to be
+        // visible to the other waves.  The min_d stores of this round are re-read by this wave alone
+        // (a bucket is streamed by its owning wave only), and same-wave accesses stay ordered, so
+        // waiting for their acknowledgements — which __syncthreads() does — is wasted serial time.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         STAMP(t4);
         {
             const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
@@ -607,7 +642,10 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
             sx = cc.x; sy = cc.y; sz = cc.z;
         }
 #ifdef PCP_FPS_STAMPS
-        { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4; }
+        { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4;
+          if (b == 0 && lane == 0 && k >= 500 && k < 503)
+              printf("[tl] k=%d wave=%2d t0=%llu test=%llu stream=%llu part=%llu bar=%llu pick=%llu n=%d\n", k, wave,
+                     t0 % 1000000ull, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, (int)__popcll(amask[0])); }
 #endif
     }
 #ifdef PCP_FPS_STAMPS

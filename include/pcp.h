@@ -131,6 +131,26 @@ int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb,
                                int32_t* pix, int64_t* offsets, int64_t cap, int32_t* overflow,
                                void* ws, size_t ws_bytes, void* stream);
 
+/*
+ * Multi-camera fusion (BASELINE config 5; the reference itself is single-camera,
+ * its frame loop XPC:96-125 run once per camera): F frames x C cameras, camera c
+ * with its own intrinsics/extrinsics cams[c] (host array of C <= PCP_MAX_CAMERAS
+ * structs).  Images are laid out (F,C,H,W) / (F,C,Hc,Wc,3); image f*C+c owns rows
+ * [offsets[f*C+c], offsets[f*C+c+1]), so the fused cloud of frame f — cameras
+ * concatenated in camera order, pixel order inside a camera — is the contiguous
+ * row range [fused_offsets[f], fused_offsets[f+1]) = [offsets[f*C], offsets[(f+1)*C]).
+ *   offsets (F*C+1) i64, fused_offsets (F+1) i64 or NULL; everything else as above.
+ * Workspace: pcp_backproject_workspace_bytes(F*C, H, W).
+ */
+#define PCP_MAX_CAMERAS 16
+int pcp_backproject_align_crop_multicam(const float* depth, const uint8_t* rgb,
+                                        int F, int C, int H, int W, int Hc, int Wc,
+                                        const pcp_params* cams,
+                                        double* xyz_cam64, double* xyz64, float* xyz32, float* rgb32,
+                                        int32_t* pix, int64_t* offsets, int64_t* fused_offsets,
+                                        int64_t cap, int32_t* overflow,
+                                        void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Stage 2 — replaces process_point_cloud DP3:23-52.
  * ------------------------------------------------------------------------- */

@@ -127,14 +127,15 @@ k1_dense(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
 }
 
 // ---- compaction pass 1: predicate ballots + tile counts ------------------------------------
-// grid (tiles, B), block 256: wave w, round r covers pixels tile*1024 + (w*4+r)*64 + lane.
+// grid (tiles, images), image b = b_first + blockIdx.y*b_stride (one camera of every frame when
+// b_stride = cameras); block 256: wave w, round r covers pixels tile*1024 + (w*4+r)*64 + lane.
 __global__ void __launch_bounds__(256)
 k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
          int Wc, DevParams P, unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt,
-         int tiles)
+         int tiles, int b_first, int b_stride)
 {
     __shared__ int wave_cnt[4];
-    const int b = blockIdx.y, tile = blockIdx.x;
+    const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
     const int lane = pcp_lane(), wave = threadIdx.x >> 6;
     const float* dframe = depth + (size_t)b * HW;
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
@@ -216,11 +217,11 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
            int Wc, DevParams P, const unsigned long long* __restrict__ masks,
            const int* __restrict__ tile_off, const long long* __restrict__ offsets, int tiles,
            double* xyz_cam64, double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
-           long long cap, int* overflow)
+           long long cap, int* overflow, int b_first, int b_stride)
 {
     __shared__ unsigned long long m[PCP_TILE_WORDS];
     __shared__ int pre[PCP_TILE_WORDS + 1];
-    const int b = blockIdx.y, tile = blockIdx.x;
+    const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
     if (threadIdx.x < PCP_TILE_WORDS)
         m[threadIdx.x] = masks[((size_t)b * tiles + tile) * PCP_TILE_WORDS + threadIdx.x];
     __syncthreads();
@@ -252,6 +253,13 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
         if (rgb32) { rgb32[3 * row] = o.col[0]; rgb32[3 * row + 1] = o.col[1]; rgb32[3 * row + 2] = o.col[2]; }
         if (pix) pix[row] = i;
     }
+}
+
+// fused (all cameras of a frame) CSR offsets: every C-th entry of the per-image offsets
+__global__ void k1_fused_offsets(const long long* __restrict__ offsets, int F, int C, long long* __restrict__ fused)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f <= F) fused[f] = offsets[(size_t)f * C];
 }
 
 // ---- host entry points -----------------------------------------------------------------------
@@ -295,16 +303,22 @@ extern "C" size_t pcp_backproject_workspace_bytes(int B, int H, int W)
            pcp_align256((size_t)B * 8) + 256;
 }
 
-extern "C" int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb, int B, int H, int W,
-                                          int Hc, int Wc, const pcp_params* p, double* xyz_cam64,
-                                          double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
-                                          int64_t* offsets, int64_t cap, int32_t* overflow, void* ws,
-                                          size_t ws_bytes, void* stream)
+// One implementation for the single-camera and the fused multi-camera entry points: images are
+// laid out (frame, camera) and camera c uses cams[c]; the flag and scatter passes are launched once
+// per camera over a strided image index, the scans once over all F*C images.
+static int backproject_align_crop_impl(const float* depth, const uint8_t* rgb, int F, int C, int H, int W,
+                                       int Hc, int Wc, const pcp_params* cams, double* xyz_cam64,
+                                       double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
+                                       int64_t* offsets, int64_t* fused_offsets, int64_t cap,
+                                       int32_t* overflow, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!depth || !params_ok(p) || !offsets || B < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || cap < 0)
+    if (!depth || !cams || !offsets || F < 0 || C <= 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || cap < 0)
         return PCP_ERR_INVALID_ARG;
+    for (int c = 0; c < C; ++c)
+        if (!params_ok(cams + c)) return PCP_ERR_INVALID_ARG;
     if (rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
-    if ((long long)H * W > 0x7fffffffLL / 4) return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4 || (long long)F * C > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
+    const int B = F * C;
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_backproject_workspace_bytes(B, H, W))
         return PCP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -319,15 +333,43 @@ extern "C" int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb
     if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
     if (B == 0) {
         PCP_HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int64_t), st));
+        if (fused_offsets) PCP_HIP_TRY(hipMemsetAsync(fused_offsets, 0, sizeof(int64_t), st));
         return PCP_OK;
     }
-    const DevParams P = pcp_to_dev(p);
-    dim3 grid(tiles, B);
-    hipLaunchKernelGGL(k1_flags, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, P, masks, tile_cnt, tiles);
+    dim3 grid(tiles, F);
+    for (int c = 0; c < C; ++c)
+        hipLaunchKernelGGL(k1_flags, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, pcp_to_dev(cams + c),
+                           masks, tile_cnt, tiles, c, C);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(B), dim3(256), 0, st, tile_cnt, tiles, frame_cnt);
     hipLaunchKernelGGL(pcp_scan_frames, dim3(1), dim3(256), 0, st, frame_cnt, B, (long long*)offsets);
-    hipLaunchKernelGGL(k1_scatter, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, P, masks, tile_cnt,
-                       (const long long*)offsets, tiles, xyz_cam64, xyz64, xyz32, rgb32, pix,
-                       (long long)cap, overflow);
+    for (int c = 0; c < C; ++c)
+        hipLaunchKernelGGL(k1_scatter, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, pcp_to_dev(cams + c),
+                           masks, tile_cnt, (const long long*)offsets, tiles, xyz_cam64, xyz64, xyz32, rgb32,
+                           pix, (long long)cap, overflow, c, C);
+    if (fused_offsets)
+        hipLaunchKernelGGL(k1_fused_offsets, dim3((F + 256) / 256), dim3(256), 0, st, (const long long*)offsets,
+                           F, C, (long long*)fused_offsets);
     return pcp_launch_status();
+}
+
+extern "C" int pcp_backproject_align_crop(const float* depth, const uint8_t* rgb, int B, int H, int W,
+                                          int Hc, int Wc, const pcp_params* p, double* xyz_cam64,
+                                          double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
+                                          int64_t* offsets, int64_t cap, int32_t* overflow, void* ws,
+                                          size_t ws_bytes, void* stream)
+{
+    return backproject_align_crop_impl(depth, rgb, B, 1, H, W, Hc, Wc, p, xyz_cam64, xyz64, xyz32, rgb32, pix,
+                                       offsets, nullptr, cap, overflow, ws, ws_bytes, stream);
+}
+
+extern "C" int pcp_backproject_align_crop_multicam(const float* depth, const uint8_t* rgb, int F, int C,
+                                                   int H, int W, int Hc, int Wc, const pcp_params* cams,
+                                                   double* xyz_cam64, double* xyz64, float* xyz32,
+                                                   float* rgb32, int32_t* pix, int64_t* offsets,
+                                                   int64_t* fused_offsets, int64_t cap, int32_t* overflow,
+                                                   void* ws, size_t ws_bytes, void* stream)
+{
+    if (C > PCP_MAX_CAMERAS) return PCP_ERR_INVALID_ARG;
+    return backproject_align_crop_impl(depth, rgb, F, C, H, W, Hc, Wc, cams, xyz_cam64, xyz64, xyz32, rgb32,
+                                       pix, offsets, fused_offsets, cap, overflow, ws, ws_bytes, stream);
 }

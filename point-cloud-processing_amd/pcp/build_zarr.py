@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Direct DP3 zarr assembly: what chunking_data.py produces, built either from the
+filtered PLYs (the reference's route, CHK:121-144) or straight from GPU results, skipping the PLY
+round trip.  State/action handling restates CHK:73-103; the zarr layout is CHK:179-200."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pcp import ply, zarr_store  # noqa: E402
+
+CHUNK_SIZE = 100            # CHK:16
+FRAME_SKIP = 1              # CHK:18
+NORMALIZE_GRIPPER = True    # CHK:21
+USE_JOINT_DELTAS = False    # CHK:25
+
+
+def load_states_actions(traj_extracted, frame_skip=FRAME_SKIP, normalize_gripper=NORMALIZE_GRIPPER,
+                        use_joint_deltas=USE_JOINT_DELTAS):
+    """CHK:73-103 → (state (n,7), action (n,7), state_indices)."""
+    action_raw = np.atleast_2d(np.loadtxt(os.path.join(traj_extracted, "actions.txt")))
+    state_raw = np.atleast_2d(np.loadtxt(os.path.join(traj_extracted, "states.txt")))
+    s_idx = np.arange(0, len(state_raw), frame_skip)
+    a_idx = np.minimum(s_idx + frame_skip - 1, len(action_raw) - 1)                  # CHK:86-87
+    state, action = state_raw[s_idx], action_raw[a_idx].copy()
+    if use_joint_deltas and action.shape[1] >= 7 and state.shape[1] >= 6:
+        action[:, :6] = action[:, :6] - state[:, :6]                                 # CHK:93-97
+    if normalize_gripper and action.shape[1] >= 7:
+        action[:, 6] = np.clip(action[:, 6] / 30.0, -1.0, 1.0)                       # CHK:100-103
+    return state, action, s_idx
+
+
+def rows_from_filtered_ply(traj_pc_path, state_indices):
+    """CHK:123-144: (n,K,6) float64 rows [xyz, colours*255] from pc_*_filtered.ply."""
+    files = sorted(f for f in os.listdir(traj_pc_path) if f.endswith("_filtered.ply"))
+    files = [files[i] for i in state_indices if i < len(files)]
+    out = []
+    for f in files:
+        pts, col = ply.read_point_cloud(os.path.join(traj_pc_path, f))
+        out.append(np.concatenate([pts, (col * 255) if col is not None else np.zeros_like(pts)], axis=1))
+    return out
+
+
+def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, compressor="zlib", intr=None,
+          ext=None):
+    """source='ply': read <traj>/filtered_point_clouds (the reference's route).
+    source='gpu': run depth+rgb of <traj>/extracted_data/<traj> through the GPU path directly."""
+    pcs, actions, states, ends, total = [], [], [], [], 0
+    runner = None
+    for traj in sorted(d for d in os.listdir(data_root) if os.path.isdir(os.path.join(data_root, d))):
+        extracted = os.path.join(data_root, traj, "extracted_data", traj)
+        need = [os.path.join(extracted, "states.txt"), os.path.join(extracted, "actions.txt"),
+                os.path.join(extracted, "camera", "rgb")]
+        pc_path = os.path.join(data_root, traj, "filtered_point_clouds")
+        if source == "ply":
+            need.append(pc_path)
+        if not all(os.path.exists(p) for p in need):
+            print(f"Skipping {traj}: Missing one or more data components.")            # CHK:67-70
+            continue
+        state, action, s_idx = load_states_actions(extracted, frame_skip)
+        if source == "ply":
+            rows = rows_from_filtered_ply(pc_path, s_idx)
+        else:
+            from pcp import _ffi, extract_point_clouds_one_cam as xpc
+            from pcp.episode import EpisodeRunner
+            intr_t = intr or xpc.extract_intrinsics(extracted, extracted)
+            d0 = np.load(os.path.join(extracted, "camera", "depth", "depth_00000.npy"))
+            if runner is None or (runner.H, runner.W) != d0.shape:
+                p = _ffi.make_params(intr_t["depth"], intr_t["color"], T=xpc.T_DEPTH_TO_COLOR, ext=ext, apply_crop=True)
+                runner = EpisodeRunner(d0.shape[0], d0.shape[1], K, p)
+            all_rows, _, ids = runner.run_tree(extracted)
+            rows = [all_rows[i] for i in s_idx if i < len(all_rows)]
+        if len(rows) != state.shape[0]:
+            print(f"Warning: {traj} has {state.shape[0]} states but {len(rows)} point clouds. Skipping.")   # CHK:127-132
+            continue
+        pcs.extend(rows); actions.append(action); states.append(state)
+        total += state.shape[0]
+        ends.append(total)                                                           # CHK:151-152
+    if not pcs:
+        raise RuntimeError("no complete trajectory found")
+    zarr_store.write_dp3_dataset(out_zarr, np.stack(pcs, axis=0), np.vstack(actions), np.vstack(states),
+                                 np.array(ends, dtype=np.int64), CHUNK_SIZE, compressor)
+    return total, len(ends)
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Assemble the DP3 zarr dataset")
+    ap.add_argument("--data_root", required=True)
+    ap.add_argument("--out_zarr", required=True)
+    ap.add_argument("--source", choices=("ply", "gpu"), default="ply")
+    ap.add_argument("--num_points", type=int, default=2500)
+    a = ap.parse_args()
+    n, e = build(a.data_root, a.out_zarr, a.source, a.num_points)
+    print(f"Saved Zarr file: {a.out_zarr}  ({n} frames, {e} episodes)")
+
+
+if __name__ == "__main__":
+    main()

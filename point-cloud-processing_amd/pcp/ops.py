@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _ffi
-from ._ffi import check, load_library
+from ._ffi import Params, check, load_library
 
 
 def _require_cuda(*tensors):
@@ -102,6 +102,30 @@ class Stage1:
             g("xyz32"), g("rgb32"), g("pix"), _ptr(self.offsets), self.cap, _ptr(self.overflow),
             _ptr(self.ws), self.ws_bytes, _stream()))
         return self.out, self.offsets
+
+
+class Stage1MultiCam(Stage1):
+    """pcp_backproject_align_crop_multicam on (F,C,H,W) batches: per-camera params, fused CSR offsets."""
+
+    def __init__(self, F, Cams, H, W, device, cap=None, want=("xyz32", "rgb32")):
+        super().__init__(F * Cams, H, W, device, cap=cap, want=want)
+        self.F, self.C = F, Cams
+        self.fused_offsets = torch.zeros(F + 1, dtype=torch.int64, device=device)
+
+    def run(self, depth, rgb, cams):
+        _require_cuda(depth, rgb)
+        _chk(depth, torch.float32, "depth"); _chk(rgb, torch.uint8, "rgb")
+        F, Cn, H, W = depth.shape
+        if (F, Cn, H, W) != (self.F, self.C, self.H, self.W) or len(cams) != Cn:
+            raise ValueError("depth shape / camera count do not match the Stage1MultiCam plan")
+        Hc, Wc = rgb.shape[2], rgb.shape[3]
+        arr = (Params * Cn)(*cams)
+        g = lambda k: _ptr(self.out.get(k))
+        check(load_library().pcp_backproject_align_crop_multicam(
+            _ptr(depth), _ptr(rgb), F, Cn, H, W, Hc, Wc, arr, g("xyz_cam64"), g("xyz64"), g("xyz32"),
+            g("rgb32"), g("pix"), _ptr(self.offsets), _ptr(self.fused_offsets), self.cap, _ptr(self.overflow),
+            _ptr(self.ws), self.ws_bytes, _stream()))
+        return self.out, self.fused_offsets, self.offsets
 
 
 def crop_mask(xyz, lo, hi):

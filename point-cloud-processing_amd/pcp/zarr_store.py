@@ -1,0 +1,107 @@
+"""Minimal zarr-v2 DirectoryStore writer/reader for the DP3 dataset layout that the reference's
+chunking_data.py creates (CHK:179-200):
+
+    <root>/data/point_cloud  (T,K,6) float32   chunks (100,K,6)
+    <root>/data/action       (T,7)   float32   chunks (100,7)
+    <root>/data/state        (T,7)   float32   chunks (100,7)
+    <root>/meta/episode_ends (E,)    int64     chunks (E,)
+
+zarr / numcodecs are not installed here, so the store is written by hand.  The reference
+compresses with Blosc-zstd (CHK:180), which needs numcodecs; this writer uses the zarr-v2
+built-in `zlib` codec (readable by any zarr installation) or no compressor at all.  Array
+names, shapes, dtypes, chunking, C order and fill value are the reference's."""
+import json
+import os
+import shutil
+import zlib
+
+import numpy as np
+
+
+def _compressor_meta(compressor):
+    if compressor in (None, "none"):
+        return None
+    if compressor == "zlib":
+        return {"id": "zlib", "level": 3}
+    raise ValueError("compressor must be None or 'zlib'")
+
+
+def _write_json(path, obj):
+    with open(path, "w") as fh:
+        json.dump(obj, fh, indent=4, sort_keys=True)
+
+
+def create_group(path):
+    os.makedirs(path, exist_ok=True)
+    _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+
+
+def write_array(path, data, chunks, dtype, compressor="zlib"):
+    """One zarr-v2 array: .zarray + one file per chunk ("i.j.k"), edge chunks zero-padded."""
+    data = np.ascontiguousarray(np.asarray(data).astype(dtype))
+    chunks = tuple(int(min(c, s)) if s > 0 else int(max(c, 1)) for c, s in zip(chunks, data.shape))
+    chunks = tuple(max(c, 1) for c in chunks)
+    os.makedirs(path, exist_ok=True)
+    dt = np.dtype(dtype)
+    meta = {"chunks": list(chunks), "compressor": _compressor_meta(compressor), "dtype": dt.str,
+            "fill_value": 0 if dt.kind in "iu" else 0.0, "filters": None, "order": "C",
+            "shape": list(data.shape), "zarr_format": 2}
+    _write_json(os.path.join(path, ".zarray"), meta)
+    grid = [-(-s // c) for s, c in zip(data.shape, chunks)]
+    for cidx in np.ndindex(*grid):
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(cidx, chunks, data.shape))
+        block = np.zeros(chunks, dtype=dt)
+        part = data[sl]
+        block[tuple(slice(0, n) for n in part.shape)] = part
+        raw = block.tobytes()
+        if meta["compressor"]:
+            raw = zlib.compress(raw, meta["compressor"]["level"])
+        with open(os.path.join(path, ".".join(str(i) for i in cidx)), "wb") as fh:
+            fh.write(raw)
+    return meta
+
+
+def read_array(path):
+    with open(os.path.join(path, ".zarray")) as fh:
+        meta = json.load(fh)
+    dt, shape, chunks = np.dtype(meta["dtype"]), tuple(meta["shape"]), tuple(meta["chunks"])
+    out = np.zeros(shape, dtype=dt)
+    grid = [-(-s // c) for s, c in zip(shape, chunks)]
+    for cidx in np.ndindex(*grid):
+        fn = os.path.join(path, ".".join(str(i) for i in cidx))
+        if not os.path.exists(fn):
+            continue
+        raw = open(fn, "rb").read()
+        comp = meta["compressor"]
+        if comp:
+            if comp["id"] != "zlib":
+                raise ValueError(f"unsupported compressor {comp['id']}")
+            raw = zlib.decompress(raw)
+        block = np.frombuffer(raw, dtype=dt).reshape(chunks)
+        sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(cidx, chunks, shape))
+        out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
+    return out, meta
+
+
+def write_dp3_dataset(out_zarr, point_cloud, action, state, episode_ends, chunk_size=100, compressor="zlib"):
+    """CHK:175-200: overwrite <out_zarr> with the DP3 layout."""
+    if os.path.exists(out_zarr):
+        print(f"Overwriting existing Zarr file: {out_zarr}")           # CHK:175-177
+        shutil.rmtree(out_zarr)
+    point_cloud, action, state = np.asarray(point_cloud), np.asarray(action), np.asarray(state)
+    episode_ends = np.asarray(episode_ends, dtype=np.int64)
+    create_group(out_zarr)
+    create_group(os.path.join(out_zarr, "data"))
+    create_group(os.path.join(out_zarr, "meta"))
+    write_array(os.path.join(out_zarr, "data", "point_cloud"), point_cloud,
+                (chunk_size,) + tuple(point_cloud.shape[1:]), "<f4", compressor)       # CHK:188,195
+    write_array(os.path.join(out_zarr, "data", "action"), action, (chunk_size, action.shape[1]), "<f4", compressor)
+    write_array(os.path.join(out_zarr, "data", "state"), state, (chunk_size, state.shape[1]), "<f4", compressor)
+    write_array(os.path.join(out_zarr, "meta", "episode_ends"), episode_ends, (max(len(episode_ends), 1),),
+                "<i8", compressor)                                                     # CHK:200
+
+
+def read_dp3_dataset(out_zarr):
+    g = lambda *p: read_array(os.path.join(out_zarr, *p))[0]
+    return dict(point_cloud=g("data", "point_cloud"), action=g("data", "action"), state=g("data", "state"),
+                episode_ends=g("meta", "episode_ends"))

@@ -1,0 +1,75 @@
+"""GPU (-m gpu): the streamed episode runner and the direct zarr assembly against
+the oracle's per-frame pipeline and against the reference's PLY route rows."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cbind, numpy_ref as R
+from helpers import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_rows(frames, intr, K):
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    rows, counts = [], []
+    for d, c in frames:
+        r = cbind.frame_pipeline(d, c, po, K, 0)
+        rows.append(cbind.pack_dp3(r["xyz"], r["rgb"]))
+        counts.append(r["M"])
+    return np.stack(rows), np.array(counts)
+
+
+def test_episode_runner_chunks_and_tail_match_oracle():
+    from pcp import _ffi
+    from pcp.episode import EpisodeRunner
+    H, W, K, T = 60, 80, 128, 23
+    intr = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    frames = [synth_frame(300 + i, H, W) for i in range(T)]
+    depth = np.stack([f[0] for f in frames]); rgb = np.stack([f[1] for f in frames])
+    runner = EpisodeRunner(H, W, K, _ffi.make_params(intr, intr, apply_crop=True), chunk=8)   # 8+8+7
+    rows, counts = runner.run_arrays(depth, rgb)
+    ref_rows, ref_counts = _oracle_rows(frames, intr, K)
+    assert rows.shape == (T, K, 6) and rows.dtype == np.float32
+    np.testing.assert_array_equal(counts, ref_counts)
+    np.testing.assert_array_equal(rows, ref_rows)
+    rows2, _ = runner.run_arrays(depth[:3], rgb[:3])                 # reuse: shorter episode, one partial chunk
+    np.testing.assert_array_equal(rows2, ref_rows[:3])
+    e, c = runner.run_arrays(depth[:0], rgb[:0])
+    assert e.shape == (0, K, 6) and c.shape == (0,)
+
+
+def test_direct_zarr_equals_ply_route_rows(tmp_path):
+    from PIL import Image
+    from pcp import build_zarr, zarr_store
+    H, W, K = 60, 80, 200
+    intr = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    root = str(tmp_path / "processed")
+    all_frames, n_per = [], [5, 3]
+    for b, n in enumerate(n_per):
+        ext = os.path.join(root, f"traj{b}", "extracted_data", f"traj{b}")
+        os.makedirs(os.path.join(ext, "camera", "rgb")); os.makedirs(os.path.join(ext, "camera", "depth"))
+        json.dump({"color": intr, "depth": intr}, open(os.path.join(ext, "intrinsics.json"), "w"))
+        for i in range(n):
+            d, c = synth_frame(500 + 10 * b + i, H, W)
+            np.save(os.path.join(ext, "camera", "depth", f"depth_{i:05d}.npy"), d)
+            Image.fromarray(c).save(os.path.join(ext, "camera", "rgb", f"rgb_{i:05d}.png"))
+            all_frames.append((d, c))
+        st = np.arange(n * 7, dtype=float).reshape(n, 7) + b
+        ac = st * 0.5; ac[:, 6] = 45.0
+        np.savetxt(os.path.join(ext, "states.txt"), st); np.savetxt(os.path.join(ext, "actions.txt"), ac)
+    os.makedirs(os.path.join(root, "traj_incomplete"))
+    out = str(tmp_path / "dp3.zarr")
+    total, eps = build_zarr.build(root, out, source="gpu", K=K, ext=R.BASE_TO_EXT_CAM_S1.reshape(4, 4))
+    assert (total, eps) == (8, 2)
+    got = zarr_store.read_dp3_dataset(out)
+    np.testing.assert_array_equal(got["episode_ends"], [5, 8])
+    assert got["point_cloud"].shape == (8, K, 6) and got["action"].shape == (8, 7)
+    assert (got["action"][:, 6] == 1.0).all()
+    # rows == what the PLY route (XPC → PLY → DP3 → PLY → CHK:134-144) yields for the same frames
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    for t, (d, c) in enumerate(all_frames):
+        r = cbind.frame_pipeline(d, c, po, K, 0)
+        np.testing.assert_array_equal(got["point_cloud"][t], R.dp3_rows(r["xyz"], r["rgb"]))

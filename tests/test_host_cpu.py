@@ -116,3 +116,42 @@ def test_no_gpu_means_loud_failure():
     import pcp.dp3_point_cloud_processing as dp3
     with pytest.raises(RuntimeError):
         dp3.farthest_point_sampling(np.zeros((10, 3)), 4)
+
+
+def test_zarr_v2_store_layout_and_roundtrip(tmp_path):
+    import json
+    from pcp import zarr_store
+    rng = np.random.default_rng(2)
+    pc = rng.normal(size=(250, 16, 6)).astype(np.float64)
+    act = rng.normal(size=(250, 7)); st = rng.normal(size=(250, 7))
+    ends = np.array([120, 250])
+    root = str(tmp_path / "d.zarr")
+    for comp in ("zlib", None):
+        zarr_store.write_dp3_dataset(root, pc, act, st, ends, compressor=comp)
+        assert json.load(open(os.path.join(root, ".zgroup"))) == {"zarr_format": 2}
+        za = json.load(open(os.path.join(root, "data", "point_cloud", ".zarray")))
+        assert za["shape"] == [250, 16, 6] and za["chunks"] == [100, 16, 6] and za["dtype"] == "<f4"   # CHK:188,195
+        assert za["order"] == "C" and za["zarr_format"] == 2 and za["filters"] is None
+        assert sorted(f for f in os.listdir(os.path.join(root, "data", "point_cloud")) if f[0] != ".") == ["0.0.0", "1.0.0", "2.0.0"]
+        ze = json.load(open(os.path.join(root, "meta", "episode_ends", ".zarray")))
+        assert ze["dtype"] == "<i8" and ze["chunks"] == [2]                                             # CHK:200
+        back = zarr_store.read_dp3_dataset(root)
+        np.testing.assert_array_equal(back["point_cloud"], pc.astype(np.float32))
+        np.testing.assert_array_equal(back["action"], act.astype(np.float32))
+        np.testing.assert_array_equal(back["episode_ends"], ends)
+
+
+def test_states_actions_frame_skip_and_gripper(tmp_path):
+    from pcp import build_zarr
+    st = np.arange(10 * 7, dtype=float).reshape(10, 7)
+    ac = st + 0.5
+    ac[:, 6] = [-30, 0, 30, 45, -60, 15, 0, 30, -30, 0]
+    np.savetxt(tmp_path / "states.txt", st, fmt="%.6f")
+    np.savetxt(tmp_path / "actions.txt", ac, fmt="%.6f")
+    s, a, idx = build_zarr.load_states_actions(str(tmp_path), frame_skip=4)
+    assert idx.tolist() == [0, 4, 8]                                   # CHK:86
+    np.testing.assert_array_equal(s, st[[0, 4, 8]])
+    np.testing.assert_array_equal(a[:, :6], ac[[3, 7, 9], :6])          # state i ↔ action i+skip-1, clamped (CHK:87)
+    assert a[:, 6].tolist() == [1.0, 1.0, 0.0]                          # /30 clipped to [-1,1] (CHK:103)
+    s1, a1, _ = build_zarr.load_states_actions(str(tmp_path), frame_skip=1)
+    assert a1[:, 6].tolist() == [-1, 0, 1, 1, -1, 0.5, 0, 1, -1, 0]

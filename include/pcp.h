@@ -218,6 +218,56 @@ int pcp_gather_rgb(const float* rgb, const int64_t* offsets, const int64_t* idx,
  */
 int pcp_pack_dp3(const float* xyz, const float* rgb, int B, int K, float* out, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Config-3 filters (BASELINE configs[2]).  The reference tree holds no voxel or
+ * outlier filter (north_star's filter_point_clouds.py is absent, SURVEY.md §0
+ * item 3); the semantics are Open3D's — the library the reference's stack calls
+ * for point-cloud work (DP3:54-58, CHK:135-142).  Parity against Open3D is
+ * UNPINNED; the GPU path is bit-exact against oracle/.
+ * Both take B clouds in CSR form (rows [offsets[b], offsets[b+1]) of xyz / rgb,
+ * offsets on the device) and write B compacted clouds in the same form.
+ * `cap_pts` is a host-known upper bound of offsets[B] (the workspace and the
+ * sort are sized by it; at most 2^32-1), `cap_out` the row capacity of the
+ * outputs; *overflow (device i32, may be NULL) is set when rows were dropped or a
+ * grid index left [0,65535] on an axis (results are then unspecified).
+ * ------------------------------------------------------------------------- */
+
+/*
+ * Open3D PointCloud::VoxelDownSample(voxel_size): per cloud, origin = min bound -
+ * voxel_size/2, voxel index = floor((p - origin)/voxel_size); every occupied voxel
+ * yields the mean point and mean colour of its members (FP64 sums in ascending
+ * row order, one division by the count).  Voxels are emitted in ascending
+ * (ix,iy,iz) order (Open3D's own order is unordered_map order, i.e. unspecified).
+ *   xyz (cap_pts,3) f64, rgb (cap_pts,3) f32 or NULL
+ *   out_xyz64 / out_xyz32 / out_rgb32 (cap_out,3), out_count (cap_out) i32: any may be NULL
+ *   out_offsets (B+1) i64
+ */
+size_t pcp_voxel_workspace_bytes(int B, int64_t cap_pts);
+int pcp_voxel_downsample(const double* xyz, const float* rgb, const int64_t* offsets, int B,
+                         int64_t cap_pts, double voxel_size,
+                         double* out_xyz64, float* out_xyz32, float* out_rgb32, int32_t* out_count,
+                         int64_t* out_offsets, int64_t cap_out, int32_t* overflow,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * Open3D PointCloud::RemoveStatisticalOutliers(nb_neighbors, std_ratio): per point
+ * the mean Euclidean distance to its min(nb_neighbors, M) nearest neighbours
+ * (itself included, FP64, ascending summation); cloud mean and sample standard
+ * deviation accumulated sequentially in row order; rows with
+ * 0 < avg < mean + std_ratio*std survive, order preserved.  1 <= nb_neighbors <= 32.
+ * `cell_size` (metres) is the edge of the uniform search grid; it only affects
+ * speed (a cell about the radius that holds nb_neighbors points is a good choice).
+ *   out_index (cap_out) i64: cloud-local source row of every survivor, or NULL
+ *   avg_dist  (cap_pts) f64: the per-point mean distances, or NULL
+ */
+size_t pcp_sor_workspace_bytes(int B, int64_t cap_pts);
+int pcp_statistical_outlier_removal(const double* xyz, const float* rgb, const int64_t* offsets, int B,
+                                    int64_t cap_pts, int nb_neighbors, double std_ratio, double cell_size,
+                                    double* out_xyz64, float* out_xyz32, float* out_rgb32,
+                                    int64_t* out_index, int64_t* out_offsets, double* avg_dist,
+                                    int64_t cap_out, int32_t* overflow,
+                                    void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

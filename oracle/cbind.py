@@ -152,3 +152,27 @@ def frame_pipeline(depth, rgb, params, K, dist_mode=0):
                                  int(dist_mode), _ptr(xyz32), _ptr(rgb32), _ptr(scratch),
                                  _ptr(idx), _ptr(oxyz), _ptr(orgb))
     return dict(M=int(m), idx=idx, xyz=oxyz, rgb=orgb)
+
+
+def voxel_downsample(xyz, rgb, voxel):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    M = xyz.shape[0]
+    rgb = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.float32)
+    o64 = np.empty((M, 3)); o32 = np.empty((M, 3), np.float32); orgb = np.empty((M, 3), np.float32)
+    cnt = np.empty(M, np.int32); clamped = C.c_int32(0)
+    f = lib().orc_voxel_downsample
+    f.restype = C.c_int64
+    nv = f(_ptr(xyz), _ptr(rgb), C.c_int64(M), C.c_double(voxel), _ptr(o64), _ptr(o32), _ptr(orgb), _ptr(cnt),
+           C.byref(clamped))
+    return dict(xyz64=o64[:nv].copy(), xyz32=o32[:nv].copy(), rgb32=orgb[:nv].copy() if rgb is not None else None,
+                count=cnt[:nv].copy(), clamped=int(clamped.value))
+
+
+def statistical_outlier(xyz, nb_neighbors=20, std_ratio=2.0):
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    M = xyz.shape[0]
+    avg = np.zeros(M); keep = np.zeros(M, np.uint8); stats = np.zeros(3)
+    f = lib().orc_statistical_outlier
+    f.restype = C.c_int64
+    kept = f(_ptr(xyz), C.c_int64(M), int(nb_neighbors), C.c_double(std_ratio), _ptr(avg), _ptr(keep), _ptr(stats))
+    return dict(keep=keep.astype(bool), avg=avg, mean=stats[0], std=stats[1], threshold=stats[2], kept=int(kept))

@@ -192,3 +192,55 @@ def dp3_rows(xyz, rgb01):
     """CHK:134-144 → one (K,6) zarr row block: [xyz, colours*255]."""
     return np.concatenate([np.asarray(xyz, dtype=np.float64),
                            ply_colour_roundtrip(rgb01) * 255], axis=1).astype(np.float32)
+
+
+# ---- config-3 filters (Open3D semantics; PARITY UNPINNED — Open3D is absent and the reference tree holds
+# ---- no voxel / outlier filter, SURVEY.md §0 item 3) ----------------------------------------------------
+def voxel_downsample(xyz, rgb, voxel):
+    """Open3D PointCloud::VoxelDownSample restated: origin = min bound - voxel/2, index = floor((p-origin)/voxel),
+    per-voxel mean with sums in ascending point order.  Voxel order (unspecified in Open3D): ascending (ix,iy,iz).
+    Returns xyz64 (V,3), rgb32 (V,3) f32, counts (V,)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    if xyz.shape[0] == 0:
+        return np.zeros((0, 3)), np.zeros((0, 3), np.float32), np.zeros((0,), np.int32)
+    origin = xyz.min(axis=0) - voxel * 0.5
+    q = np.clip(np.floor((xyz - origin) / voxel), 0, 65535).astype(np.int64)
+    key = (q[:, 0] << 32) | (q[:, 1] << 16) | q[:, 2]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    gid = np.cumsum(np.r_[True, ks[1:] != ks[:-1]]) - 1
+    nv = int(gid[-1]) + 1
+    s = np.zeros((nv, 3)); c = np.zeros((nv, 3))
+    np.add.at(s, gid, xyz[order])                                  # ufunc.at: unbuffered, strictly in order
+    if rgb is not None:
+        np.add.at(c, gid, np.asarray(rgb, dtype=np.float32).astype(np.float64)[order])
+    cnt = np.bincount(gid, minlength=nv)
+    return s / cnt[:, None], (c / cnt[:, None]).astype(np.float32), cnt.astype(np.int32)
+
+
+def statistical_outlier(xyz, nb_neighbors=20, std_ratio=2.0):
+    """Open3D PointCloud::RemoveStatisticalOutliers restated (brute-force KNN, self included).
+    Returns keep mask, avg distances, (mean, std, threshold).  Small clouds only (O(M^2) memory)."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    M = xyz.shape[0]
+    d = xyz[:, None, :] - xyz[None, :, :]
+    d2 = ((d[..., 0] * d[..., 0]) + (d[..., 1] * d[..., 1])) + (d[..., 2] * d[..., 2])
+    k = min(nb_neighbors, M)
+    near = np.sqrt(np.sort(d2, axis=1)[:, :k])
+    avg = np.zeros(M)
+    for t in range(k):                                             # sequential, ascending distance
+        avg = avg + near[:, t]
+    avg = avg / float(k)
+    total = 0.0
+    for v in avg:
+        if v > 0:
+            total = total + v
+    mean = total / M
+    sq = 0.0
+    for v in avg:
+        if v > 0:
+            sq = sq + (v - mean) * (v - mean)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        std = float(np.sqrt(np.float64(sq) / np.float64(M - 1)))
+    thr = mean + std_ratio * std
+    return (avg > 0) & (avg < thr), avg, (mean, std, thr)

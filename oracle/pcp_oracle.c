@@ -245,3 +245,112 @@ int64_t orc_frame_pipeline(const float* depth, const uint8_t* rgb, int H, int W,
     orc_gather_rgb(rgb32, M, idx, K, 1, out_rgb);
     return M;
 }
+
+/* ------------------------------------------------------------------------------------------- *
+ * Config-3 filters.  The reference tree has no voxel / outlier filter; the
+ * semantics restated here are Open3D's PointCloud::VoxelDownSample and
+ * PointCloud::RemoveStatisticalOutliers (the library the reference's stack uses), from their
+ * published algorithm.  PARITY UNPINNED: Open3D is absent, no fixture of the reference covers them.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t key; int64_t idx; } orc_kv;
+
+static int orc_kv_cmp(const void* a, const void* b)
+{
+    const orc_kv *p = (const orc_kv*)a, *q = (const orc_kv*)b;
+    if (p->key != q->key) return p->key < q->key ? -1 : 1;
+    return p->idx < q->idx ? -1 : (p->idx > q->idx);
+}
+
+/* VoxelDownSample: origin = min bound - voxel/2; index = floor((p-origin)/voxel); mean of points and
+ * colours per voxel, sums in ascending point order; voxels emitted in ascending (ix,iy,iz) (Open3D's
+ * own order is unordered_map order, i.e. unspecified).  Returns the voxel count; *clamped is set when
+ * an index left [0,65535]. */
+int64_t orc_voxel_downsample(const double* xyz, const float* rgb, int64_t M, double voxel, double* out64,
+                             float* out32, float* out_rgb, int32_t* out_cnt, int32_t* clamped)
+{
+    if (clamped) *clamped = 0;
+    if (M <= 0) return 0;
+    double mn[3] = {xyz[0], xyz[1], xyz[2]};
+    for (int64_t i = 1; i < M; ++i)
+        for (int c = 0; c < 3; ++c) if (xyz[3 * i + c] < mn[c]) mn[c] = xyz[3 * i + c];
+    orc_kv* kv = (orc_kv*)malloc((size_t)M * sizeof(orc_kv));
+    for (int64_t i = 0; i < M; ++i) {
+        uint64_t key = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double origin = mn[c] - voxel * 0.5;
+            const double r = floor((xyz[3 * i + c] - origin) / voxel);
+            long long q = (long long)r;
+            if (!(r >= 0.0) || r > 65535.0) { if (clamped) *clamped = 1; q = r > 0.0 ? 65535 : 0; }
+            key |= (uint64_t)q << (16 * (2 - c));
+        }
+        kv[i].key = key; kv[i].idx = i;
+    }
+    qsort(kv, (size_t)M, sizeof(orc_kv), orc_kv_cmp);
+    int64_t nv = 0;
+    for (int64_t j = 0; j < M;) {
+        double s[3] = {0, 0, 0}, cs[3] = {0, 0, 0};
+        int cnt = 0;
+        int64_t e = j;
+        for (; e < M && kv[e].key == kv[j].key; ++e) {
+            const int64_t i = kv[e].idx;
+            for (int c = 0; c < 3; ++c) { s[c] += xyz[3 * i + c]; if (rgb) cs[c] += (double)rgb[3 * i + c]; }
+            ++cnt;
+        }
+        for (int c = 0; c < 3; ++c) {
+            const double a = s[c] / (double)cnt;
+            if (out64) out64[3 * nv + c] = a;
+            if (out32) out32[3 * nv + c] = (float)a;
+            if (out_rgb) out_rgb[3 * nv + c] = (float)(cs[c] / (double)cnt);
+        }
+        if (out_cnt) out_cnt[nv] = cnt;
+        ++nv;
+        j = e;
+    }
+    free(kv);
+    return nv;
+}
+
+/* RemoveStatisticalOutliers(nb_neighbors, std_ratio): per point the mean of sqrt(d2) over its
+ * min(nb, M) nearest neighbours INCLUDING itself, d2 = ((dx*dx)+(dy*dy))+(dz*dz) in f64, summed in
+ * ascending order; cloud mean / sample standard deviation accumulated sequentially in point order;
+ * keep avg > 0 && avg < mean + std_ratio*std.  Brute force O(M^2).  Returns the kept count. */
+int64_t orc_statistical_outlier(const double* xyz, int64_t M, int nb, double std_ratio, double* avg,
+                                uint8_t* keep, double* stats /* mean, std, threshold */)
+{
+    if (M <= 0 || nb < 1) return 0;
+    double* best = (double*)malloc((size_t)nb * sizeof(double));
+    int64_t valid = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        int n = 0;
+        for (int64_t j = 0; j < M; ++j) {
+            const double dx = xyz[3 * i] - xyz[3 * j], dy = xyz[3 * i + 1] - xyz[3 * j + 1],
+                         dz = xyz[3 * i + 2] - xyz[3 * j + 2];
+            const double d = ((dx * dx) + (dy * dy)) + (dz * dz);
+            if (n < nb) {
+                int p = n++;
+                while (p > 0 && best[p - 1] > d) { best[p] = best[p - 1]; --p; }
+                best[p] = d;
+            } else if (d < best[nb - 1]) {
+                int p = nb - 1;
+                while (p > 0 && best[p - 1] > d) { best[p] = best[p - 1]; --p; }
+                best[p] = d;
+            }
+        }
+        double s = 0.0;
+        for (int t = 0; t < n; ++t) s += sqrt(best[t]);
+        avg[i] = s / (double)n;
+        ++valid;
+    }
+    free(best);
+    double sum = 0.0;
+    for (int64_t i = 0; i < M; ++i) if (avg[i] > 0) sum = sum + avg[i];
+    const double mean = sum / (double)valid;
+    double sq = 0.0;
+    for (int64_t i = 0; i < M; ++i) if (avg[i] > 0) sq = sq + (avg[i] - mean) * (avg[i] - mean);
+    const double sd = sqrt(sq / (double)(valid - 1));
+    const double thr = mean + std_ratio * sd;
+    int64_t kept = 0;
+    for (int64_t i = 0; i < M; ++i) { keep[i] = (avg[i] > 0 && avg[i] < thr) ? 1 : 0; kept += keep[i]; }
+    if (stats) { stats[0] = mean; stats[1] = sd; stats[2] = thr; }
+    return kept;
+}

@@ -3,3 +3,5 @@
 #include "crop.hip"
 #include "fps.hip"
 #include "misc.hip"
+#include "voxel.hip"
+#include "sor.hip"

@@ -1,0 +1,299 @@
+// Statistical outlier removal of B CSR clouds on gfx950 (BASELINE config 3).
+//
+// Semantics: Open3D's PointCloud::RemoveStatisticalOutliers(nb_neighbors, std_ratio) — the reference
+// tree has no outlier filter of its own.  For every point the mean of sqrt(d2)
+// over its min(nb, M) nearest neighbours INCLUDING itself, d2 = ((dx*dx)+(dy*dy))+(dz*dz) in FP64
+// (nanoflann L2 order), summed in ascending order; cloud mean and sample standard deviation
+// accumulated strictly sequentially in point order (std::accumulate / std::inner_product); keep
+// avg > 0 && avg < mean + std_ratio*std, order preserved.  PARITY UNPINNED against Open3D (absent
+// here); bit-exact against the CPU restatement the tests hold — the k smallest distances are a multiset, so the KNN search
+// strategy (grid here, kd-tree in Open3D, brute force in the tests) cannot change the result.
+//
+// Pipeline: uniform grid of `cell` metres keyed like the voxel filter (cloud | ix | iy | iz), stable
+// radix sort, points gathered into sorted order; one thread per sorted point scans the x-slabs of the
+// (2r+1)^3 neighbourhood for r = 1..3 until the k-th distance is provably inside the scanned block,
+// else falls back to the whole cloud; one wave per cloud does the sequential statistics; the keep
+// flags are compacted with the ballot / tile-scan machinery.
+#include "pcp_internal.h"
+#include <float.h>
+
+#define SOR_RMAX 3
+
+__global__ void __launch_bounds__(256)
+sor_gather_sorted(const double* __restrict__ xyz, const unsigned int* __restrict__ vals,
+                  const long long* __restrict__ offsets, int B, double* __restrict__ sxyz)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= offsets[B]) return;
+    const size_t i = vals[j];
+    sxyz[3 * j] = xyz[3 * i]; sxyz[3 * j + 1] = xyz[3 * i + 1]; sxyz[3 * j + 2] = xyz[3 * i + 2];
+}
+
+template <int KCAP>
+__device__ __forceinline__ void sor_insert(double (&best)[KCAP], double d)
+{
+    if (d < best[KCAP - 1]) {
+#pragma unroll
+        for (int t = KCAP - 1; t > 0; --t) {
+            const double lo = best[t - 1];
+            best[t] = lo > d ? lo : (best[t] > d ? d : best[t]);
+        }
+        best[0] = best[0] > d ? d : best[0];
+    }
+}
+
+template <int KCAP>
+__device__ __forceinline__ double sor_kth(const double (&best)[KCAP], int k)
+{
+    double v = best[0];
+#pragma unroll
+    for (int t = 1; t < KCAP; ++t) v = (t == k - 1) ? best[t] : v;
+    return v;
+}
+
+// first sorted position in [lo,hi) whose key is >= key
+__device__ __forceinline__ long long sor_lower_bound(const unsigned long long* __restrict__ keys, long long lo,
+                                                     long long hi, unsigned long long key)
+{
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int KCAP>
+__global__ void __launch_bounds__(256)
+sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
+        const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
+        int nb, double* __restrict__ avg)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= offsets[B]) return;
+    const unsigned long long key = keys[j];
+    const int b = (int)(key >> 48);
+    const int cx = (int)((key >> 32) & 0xFFFF), cy = (int)((key >> 16) & 0xFFFF), cz = (int)(key & 0xFFFF);
+    const long long lo = offsets[b], hi = offsets[b + 1];
+    const long long M = hi - lo;
+    const int k = (long long)nb < M ? nb : (int)M;
+    const double px = sxyz[3 * j], py = sxyz[3 * j + 1], pz = sxyz[3 * j + 2];
+    const unsigned long long cloud = (unsigned long long)b << 48;
+    double best[KCAP];
+    bool done = false;
+    if (M > k) {
+        for (int r = 1; r <= SOR_RMAX && !done; ++r) {
+#pragma unroll
+            for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+            const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > 65535 ? 65535 : cy + r;
+            for (int x = cx - r; x <= cx + r; ++x) {
+                if (x < 0 || x > 65535) continue;
+                const unsigned long long k0 = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y0 << 16);
+                const unsigned long long k1 = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y1 << 16) | 0xFFFFull;
+                for (long long t = sor_lower_bound(keys, lo, hi, k0); t < hi; ++t) {
+                    const unsigned long long kt = keys[t];
+                    if (kt > k1) break;
+                    const int dzc = (int)(kt & 0xFFFF) - cz;
+                    if (dzc > r || dzc < -r) continue;
+                    const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
+                    sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+                }
+            }
+            const double lim = ((double)r * cell) * (1.0 - 1e-9);      // every point closer than this was scanned
+            done = sor_kth<KCAP>(best, k) <= lim * lim;
+        }
+    }
+    if (!done) {                                                     // isolated point or tiny cloud: whole cloud
+#pragma unroll
+        for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+        for (long long t = lo; t < hi; ++t) {
+            const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
+            sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < KCAP; ++t)
+        if (t < k) s += sqrt(best[t]);
+    avg[vals[j]] = s / (double)k;
+}
+
+// One wave per cloud: strictly sequential sums (point order), as std::accumulate does.
+// stats[b] = {mean, std, threshold, 0}
+__global__ void __launch_bounds__(64)
+sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets, double std_ratio,
+          double* __restrict__ stats)
+{
+    const int b = blockIdx.x, lane = pcp_lane();
+    const long long lo = offsets[b], hi = offsets[b + 1];
+    const long long M = hi - lo;
+    double res[2] = {0.0, 0.0};
+    double mean = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double acc = 0.0;
+        double nxt = lo + lane < hi ? avg[lo + lane] : 0.0;
+        for (long long base = lo; base < hi; base += 64) {
+            const double v = nxt;
+            const long long ni = base + 64 + lane;
+            nxt = ni < hi ? avg[ni] : 0.0;                            // prefetch under the serial chain
+#pragma unroll
+            for (int t = 0; t < 64; ++t) {
+                const double y = __shfl(v, t, 64);
+                if (pass == 0) acc = y > 0.0 ? acc + y : acc;
+                else acc = y > 0.0 ? acc + (y - mean) * (y - mean) : acc;
+            }
+        }
+        res[pass] = acc;
+        if (pass == 0) mean = acc / (double)M;
+    }
+    if (lane == 0) {
+        const double sd = sqrt(res[1] / (double)(M - 1));
+        stats[4 * b] = mean; stats[4 * b + 1] = sd; stats[4 * b + 2] = mean + std_ratio * sd; stats[4 * b + 3] = 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sor_flags(const double* __restrict__ avg, const long long* __restrict__ offsets, int B,
+          const double* __restrict__ stats, unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt)
+{
+    __shared__ int wave_cnt[4];
+    const long long n = offsets[B];
+    const int lane = pcp_lane(), wave = threadIdx.x >> 6;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int word = wave * 4 + r;
+        const long long i = (long long)blockIdx.x * PCP_TILE + word * 64 + lane;
+        int keep = 0;
+        if (i < n) {
+            const int b = vox_cloud_of(offsets, B, i);
+            const double a = avg[i];
+            keep = a > 0.0 && a < stats[4 * b + 2];
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) masks[(size_t)blockIdx.x * PCP_TILE_WORDS + word] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) wave_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ void __launch_bounds__(256)
+sor_scatter(const double* __restrict__ xyz, const float* __restrict__ rgb, const long long* __restrict__ offsets,
+            int B, const unsigned long long* __restrict__ masks, const int* __restrict__ tile_off, double* out64,
+            float* out32, float* out_rgb, long long* out_index, long long cap_out, int* overflow)
+{
+    __shared__ unsigned long long m[PCP_TILE_WORDS];
+    __shared__ int pre[PCP_TILE_WORDS + 1];
+    const int tile = blockIdx.x;
+    if (threadIdx.x < PCP_TILE_WORDS) m[threadIdx.x] = masks[(size_t)tile * PCP_TILE_WORDS + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < PCP_TILE_WORDS; ++w) { pre[w] = acc; acc += __popcll(m[w]); }
+        pre[PCP_TILE_WORDS] = acc;
+    }
+    __syncthreads();
+    const int nk = pre[PCP_TILE_WORDS];
+    for (int t = threadIdx.x; t < nk; t += blockDim.x) {
+        int w = 0;
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1)
+            if (pre[w + s] <= t) w += s;
+        const long long i = (long long)tile * PCP_TILE + w * 64 + pcp_select_bit(m[w], t - pre[w]);
+        const long long row = (long long)tile_off[tile] + t;
+        if (row >= cap_out) { if (overflow) *overflow = 1; continue; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double v = xyz[3 * i + c];
+            if (out64) out64[3 * row + c] = v;
+            if (out32) out32[3 * row + c] = (float)v;
+            if (out_rgb) out_rgb[3 * row + c] = rgb[3 * i + c];
+        }
+        if (out_index) out_index[row] = i - offsets[vox_cloud_of(offsets, B, i)];
+    }
+}
+
+struct SorLayout { VoxLayout v; size_t sxyz, avg, stats, end; };
+
+static SorLayout sor_layout(int B, int64_t cap)
+{
+    SorLayout L;
+    L.v = vox_layout(B, cap);
+    const size_t n = (size_t)(cap > 0 ? cap : 1);
+    size_t o = L.v.end;
+    L.sxyz = o;  o += pcp_align256(n * 24);
+    L.avg = o;   o += pcp_align256(n * 8);
+    L.stats = o; o += pcp_align256((size_t)(B > 0 ? B : 1) * 32);
+    L.end = o;
+    return L;
+}
+
+extern "C" size_t pcp_sor_workspace_bytes(int B, int64_t cap_pts)
+{
+    if (B < 0 || cap_pts < 0) return 0;
+    return sor_layout(B, cap_pts).end;
+}
+
+extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* rgb, const int64_t* offsets,
+                                               int B, int64_t cap_pts, int nb_neighbors, double std_ratio,
+                                               double cell_size, double* out_xyz64, float* out_xyz32,
+                                               float* out_rgb32, int64_t* out_index, int64_t* out_offsets,
+                                               double* avg_dist, int64_t cap_out, int32_t* overflow, void* ws,
+                                               size_t ws_bytes, void* stream)
+{
+    if (!offsets || !out_offsets || B < 0 || B > 65534 || cap_pts < 0 || cap_pts > 0xFFFFFFFFLL || cap_out < 0 ||
+        nb_neighbors < 1 || nb_neighbors > 32 || !(cell_size > 0.0))
+        return PCP_ERR_INVALID_ARG;
+    if (cap_pts > 0 && !xyz) return PCP_ERR_INVALID_ARG;
+    if (out_rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (B == 0 || cap_pts == 0) {
+        PCP_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(B + 1), st));
+        return PCP_OK;
+    }
+    const SorLayout L = sor_layout(B, cap_pts);
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < L.end) return PCP_ERR_WORKSPACE;
+    char* w = (char*)ws;
+    unsigned long long* minb = (unsigned long long*)(w + L.v.minb);
+    unsigned long long* keys_in = (unsigned long long*)(w + L.v.keys_in);
+    unsigned long long* keys_out = (unsigned long long*)(w + L.v.keys_out);
+    unsigned int* vals_in = (unsigned int*)(w + L.v.vals_in);
+    unsigned int* vals_out = (unsigned int*)(w + L.v.vals_out);
+    unsigned long long* masks = (unsigned long long*)(w + L.v.masks);
+    int* tile_cnt = (int*)(w + L.v.tile_cnt);
+    long long* total = (long long*)(w + L.v.total);
+    double* sxyz = (double*)(w + L.sxyz);
+    double* avg = avg_dist ? avg_dist : (double*)(w + L.avg);
+    double* stats = (double*)(w + L.stats);
+    const long long* off = (const long long*)offsets;
+    const unsigned nblk = (unsigned)((cap_pts + 255) / 256);
+    const int tiles = (int)((cap_pts + PCP_TILE - 1) / PCP_TILE);
+
+    PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
+    hipLaunchKernelGGL(vox_minbound, dim3(nblk), dim3(256), 0, st, xyz, off, B, minb);
+    hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, cell_size,
+                       keys_in, vals_in, overflow);
+    size_t temp_bytes = L.v.temp_bytes;
+    PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.v.temp), temp_bytes, (const unsigned long long*)keys_in,
+                                          keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
+                                          64u, st));
+    hipLaunchKernelGGL(sor_gather_sorted, dim3(nblk), dim3(256), 0, st, xyz, vals_out, off, B, sxyz);
+    if (nb_neighbors <= 8)
+        hipLaunchKernelGGL(sor_knn<8>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+    else if (nb_neighbors <= 16)
+        hipLaunchKernelGGL(sor_knn<16>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+    else if (nb_neighbors <= 24)
+        hipLaunchKernelGGL(sor_knn<24>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+    else
+        hipLaunchKernelGGL(sor_knn<32>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+    hipLaunchKernelGGL(sor_stats, dim3(B), dim3(64), 0, st, avg, off, std_ratio, stats);
+    hipLaunchKernelGGL(sor_flags, dim3(tiles), dim3(256), 0, st, avg, off, B, stats, masks, tile_cnt);
+    hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
+    hipLaunchKernelGGL(sor_scatter, dim3(tiles), dim3(256), 0, st, xyz, rgb, off, B, masks, tile_cnt, out_xyz64,
+                       out_xyz32, out_rgb32, (long long*)out_index, (long long)cap_out, overflow);
+    hipLaunchKernelGGL(vox_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
+                       (long long*)out_offsets);
+    return pcp_launch_status();
+}

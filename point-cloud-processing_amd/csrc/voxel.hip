@@ -1,0 +1,285 @@
+// Voxel-grid downsample of B CSR clouds on gfx950 (BASELINE config 3).
+//
+// The reference has no voxel filter of its own (its filter_point_clouds step is absent from the
+// tree), so the semantics are Open3D's PointCloud::VoxelDownSample, which the
+// reference's stack would call: origin = per-cloud min bound − voxel/2, voxel index =
+// floor((p − origin)/voxel) per axis, every occupied voxel yields the mean of its points and
+// colours, FP64 sums accumulated in ascending point order, then one true division by the count.
+// Open3D emits voxels in std::unordered_map order (unspecified); this build defines the order as
+// ascending (ix, iy, iz).  PARITY UNPINNED against Open3D (absent here); bit-exact against the CPU restatement the tests hold.
+//
+// Pipeline (all on the caller's stream):
+//   vox_minbound : per-cloud FP64 min via wave reduction + one ordered-u64 atomicMin per wave
+//   vox_keys     : key = cloud<<48 | ix<<32 | iy<<16 | iz, value = point row
+//   rocprim::radix_sort_pairs (stable → rows ascending inside a voxel)
+//   vox_heads    : ballot of "first row of a voxel" per 64 sorted rows + counts per 1024-row tile
+//   pcp_scan_tiles (one sequence)
+//   vox_reduce   : thread t of a tile owns the tile's t-th voxel: walks its run, sums in order, divides
+//   vox_offsets  : CSR offsets of the output clouds from the ballots
+#include "pcp_internal.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#define VOX_AXIS_MAX 65535
+#define VOX_KEY_PAD 0xFFFFFFFFFFFFFFFFull
+
+// order-preserving map double <-> u64 (so unsigned atomicMin is a floating-point min)
+__device__ __forceinline__ unsigned long long vox_ord(double d)
+{
+    unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double vox_unord(unsigned long long u)
+{
+    u = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+    return __longlong_as_double((long long)u);
+}
+
+// cloud that owns row i: largest b with offsets[b] <= i
+__device__ __forceinline__ int vox_cloud_of(const long long* __restrict__ offsets, int B, long long i)
+{
+    int lo = 0, hi = B;                       // invariant: offsets[lo] <= i < offsets[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+vox_minbound(const double* __restrict__ xyz, const long long* __restrict__ offsets, int B,
+             unsigned long long* __restrict__ minb)
+{
+    const long long n = offsets[B];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const long long ic = live ? i : (n > 0 ? n - 1 : 0);
+    int b = 0;
+    double p[3] = {0.0, 0.0, 0.0};
+    if (n > 0) {
+        b = vox_cloud_of(offsets, B, ic);
+        p[0] = xyz[3 * ic]; p[1] = xyz[3 * ic + 1]; p[2] = xyz[3 * ic + 2];
+    }
+    if (n <= 0) return;
+    const int b0 = __builtin_amdgcn_readfirstlane(b);
+    if (__all(b == b0)) {                      // the usual case: one cloud per wave → 3 atomics per wave
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = p[c];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double o = __shfl_xor(v, d, 64);
+                v = o < v ? o : v;
+            }
+            if (pcp_lane() == 0) atomicMin(&minb[3 * b0 + c], vox_ord(v));
+        }
+    } else if (live) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) atomicMin(&minb[3 * b + c], vox_ord(p[c]));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+vox_keys(const double* __restrict__ xyz, const long long* __restrict__ offsets, int B, long long cap,
+         const unsigned long long* __restrict__ minb, double voxel, unsigned long long* __restrict__ keys,
+         unsigned int* __restrict__ vals, int* __restrict__ overflow)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const long long n = offsets[B];
+    vals[i] = (unsigned int)i;
+    if (i >= n) { keys[i] = VOX_KEY_PAD; return; }
+    const int b = vox_cloud_of(offsets, B, i);
+    unsigned long long key = (unsigned long long)b << 48;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double origin = vox_unord(minb[3 * b + c]) - voxel * 0.5;     // GetMinBound() - voxel_size*0.5
+        const double r = floor((xyz[3 * i + c] - origin) / voxel);
+        long long q = (long long)r;
+        if (!(r >= 0.0) || r > (double)VOX_AXIS_MAX) { bad = true; q = r > 0.0 ? VOX_AXIS_MAX : 0; }
+        key |= (unsigned long long)q << (16 * (2 - c));
+    }
+    if (bad && overflow) *overflow = 1;
+    keys[i] = key;
+}
+
+// grid: tiles of 1024 sorted rows; block 256 (wave w, round r → word w*4+r)
+__global__ void __launch_bounds__(256)
+vox_heads(const unsigned long long* __restrict__ keys, const long long* __restrict__ offsets, int B,
+          unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt)
+{
+    __shared__ int wave_cnt[4];
+    const long long n = offsets[B];
+    const int lane = pcp_lane(), wave = threadIdx.x >> 6;
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int word = wave * 4 + r;
+        const long long j = (long long)blockIdx.x * PCP_TILE + word * 64 + lane;
+        int head = 0;
+        if (j < n) head = (j == 0) || (keys[j] != keys[j - 1]);
+        const unsigned long long m = __ballot(head);
+        if (lane == 0) masks[(size_t)blockIdx.x * PCP_TILE_WORDS + word] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) wave_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+__global__ void __launch_bounds__(256)
+vox_reduce(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ vals,
+           const double* __restrict__ xyz, const float* __restrict__ rgb,
+           const long long* __restrict__ offsets, int B, const unsigned long long* __restrict__ masks,
+           const int* __restrict__ tile_off, double* out64, float* out32, float* out_rgb, int32_t* out_cnt,
+           long long cap_out, int* overflow)
+{
+    __shared__ unsigned long long m[PCP_TILE_WORDS];
+    __shared__ int pre[PCP_TILE_WORDS + 1];
+    const int tile = blockIdx.x;
+    if (threadIdx.x < PCP_TILE_WORDS) m[threadIdx.x] = masks[(size_t)tile * PCP_TILE_WORDS + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int w = 0; w < PCP_TILE_WORDS; ++w) { pre[w] = acc; acc += __popcll(m[w]); }
+        pre[PCP_TILE_WORDS] = acc;
+    }
+    __syncthreads();
+    const int nh = pre[PCP_TILE_WORDS];
+    const long long n = offsets[B];
+    for (int t = threadIdx.x; t < nh; t += blockDim.x) {
+        int w = 0;
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1)
+            if (pre[w + s] <= t) w += s;
+        const int bit = pcp_select_bit(m[w], t - pre[w]);
+        const long long j0 = (long long)tile * PCP_TILE + w * 64 + bit;
+        const long long row = (long long)tile_off[tile] + t;
+        if (row >= cap_out) { if (overflow) *overflow = 1; continue; }
+        const unsigned long long key = keys[j0];
+        double s[3] = {0.0, 0.0, 0.0}, c[3] = {0.0, 0.0, 0.0};
+        int cnt = 0;
+        for (long long j = j0; j < n && keys[j] == key; ++j) {      // rows ascending (stable sort)
+            const size_t i = vals[j];
+            s[0] += xyz[3 * i]; s[1] += xyz[3 * i + 1]; s[2] += xyz[3 * i + 2];
+            if (rgb) { c[0] += (double)rgb[3 * i]; c[1] += (double)rgb[3 * i + 1]; c[2] += (double)rgb[3 * i + 2]; }
+            ++cnt;
+        }
+        const double dn = (double)cnt;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double a = s[k] / dn;
+            if (out64) out64[3 * row + k] = a;
+            if (out32) out32[3 * row + k] = (float)a;
+            if (out_rgb) out_rgb[3 * row + k] = (float)(c[k] / dn);
+        }
+        if (out_cnt) out_cnt[row] = cnt;
+    }
+}
+
+// out_offsets[b] = number of voxel heads before sorted position offsets[b]
+__global__ void vox_offsets(const long long* __restrict__ offsets, int B,
+                            const unsigned long long* __restrict__ masks, const int* __restrict__ tile_off,
+                            const long long* __restrict__ total_heads, long long* __restrict__ out_offsets)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    const long long p = offsets[b], n = offsets[B];
+    if (p >= n) { out_offsets[b] = total_heads[0]; return; }
+    const long long tile = p / PCP_TILE;
+    const int in_tile = (int)(p % PCP_TILE), word = in_tile >> 6, bit = in_tile & 63;
+    long long r = tile_off[tile];
+    for (int w = 0; w < word; ++w) r += __popcll(masks[(size_t)tile * PCP_TILE_WORDS + w]);
+    const unsigned long long low = bit ? (masks[(size_t)tile * PCP_TILE_WORDS + word] & ((1ull << bit) - 1ull)) : 0ull;
+    out_offsets[b] = r + __popcll(low);
+}
+
+static size_t vox_sort_temp_bytes(int64_t cap)
+{
+    size_t bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr,
+                                             (unsigned long long*)nullptr, (const unsigned int*)nullptr,
+                                             (unsigned int*)nullptr, (size_t)cap, 0u, 64u, (hipStream_t)0);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return bytes;
+}
+
+struct VoxLayout {
+    size_t minb, keys_in, keys_out, vals_in, vals_out, masks, tile_cnt, total, temp, temp_bytes, end;
+};
+
+static VoxLayout vox_layout(int B, int64_t cap)
+{
+    VoxLayout L;
+    const size_t n = (size_t)(cap > 0 ? cap : 1), tiles = (n + PCP_TILE - 1) / PCP_TILE;
+    size_t o = 0;
+    L.minb = o;     o += pcp_align256((size_t)(B > 0 ? B : 1) * 3 * 8);
+    L.keys_in = o;  o += pcp_align256(n * 8);
+    L.keys_out = o; o += pcp_align256(n * 8);
+    L.vals_in = o;  o += pcp_align256(n * 4);
+    L.vals_out = o; o += pcp_align256(n * 4);
+    L.masks = o;    o += pcp_align256(tiles * PCP_TILE_WORDS * 8);
+    L.tile_cnt = o; o += pcp_align256(tiles * 4);
+    L.total = o;    o += 256;
+    L.temp = o;
+    L.temp_bytes = vox_sort_temp_bytes((int64_t)n);
+    o += pcp_align256(L.temp_bytes) + 256;
+    L.end = o;
+    return L;
+}
+
+extern "C" size_t pcp_voxel_workspace_bytes(int B, int64_t cap_pts)
+{
+    if (B < 0 || cap_pts < 0) return 0;
+    return vox_layout(B, cap_pts).end;
+}
+
+extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const int64_t* offsets, int B,
+                                    int64_t cap_pts, double voxel_size, double* out_xyz64, float* out_xyz32,
+                                    float* out_rgb32, int32_t* out_count, int64_t* out_offsets,
+                                    int64_t cap_out, int32_t* overflow, void* ws, size_t ws_bytes,
+                                    void* stream)
+{
+    if (!offsets || !out_offsets || B < 0 || B > 65534 || cap_pts < 0 || cap_pts > 0xFFFFFFFFLL || cap_out < 0 ||
+        !(voxel_size > 0.0))
+        return PCP_ERR_INVALID_ARG;
+    if (cap_pts > 0 && !xyz) return PCP_ERR_INVALID_ARG;
+    if (out_rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (B == 0 || cap_pts == 0) {
+        PCP_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(B + 1), st));
+        return PCP_OK;
+    }
+    const VoxLayout L = vox_layout(B, cap_pts);
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < L.end) return PCP_ERR_WORKSPACE;
+    char* w = (char*)ws;
+    unsigned long long* minb = (unsigned long long*)(w + L.minb);
+    unsigned long long* keys_in = (unsigned long long*)(w + L.keys_in);
+    unsigned long long* keys_out = (unsigned long long*)(w + L.keys_out);
+    unsigned int* vals_in = (unsigned int*)(w + L.vals_in);
+    unsigned int* vals_out = (unsigned int*)(w + L.vals_out);
+    unsigned long long* masks = (unsigned long long*)(w + L.masks);
+    int* tile_cnt = (int*)(w + L.tile_cnt);
+    long long* total = (long long*)(w + L.total);
+    const long long* off = (const long long*)offsets;
+    const unsigned nblk = (unsigned)((cap_pts + 255) / 256);
+    const int tiles = (int)((cap_pts + PCP_TILE - 1) / PCP_TILE);
+
+    PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
+    hipLaunchKernelGGL(vox_minbound, dim3(nblk), dim3(256), 0, st, xyz, off, B, minb);
+    hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, voxel_size,
+                       keys_in, vals_in, overflow);
+    size_t temp_bytes = L.temp_bytes;
+    PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.temp), temp_bytes, (const unsigned long long*)keys_in,
+                                          keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
+                                          64u, st));
+    hipLaunchKernelGGL(vox_heads, dim3(tiles), dim3(256), 0, st, keys_out, off, B, masks, tile_cnt);
+    hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
+    hipLaunchKernelGGL(vox_reduce, dim3(tiles), dim3(256), 0, st, keys_out, vals_out, xyz, rgb, off, B, masks,
+                       tile_cnt, out_xyz64, out_xyz32, out_rgb32, out_count, (long long)cap_out, overflow);
+    hipLaunchKernelGGL(vox_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
+                       (long long*)out_offsets);
+    return pcp_launch_status();
+}

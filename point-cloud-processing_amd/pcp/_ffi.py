@@ -12,6 +12,7 @@ EXPORTS = (
     "pcp_backproject_align_crop_multicam",
     "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact",
     "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_gather_rgb", "pcp_pack_dp3",
+    "pcp_voxel_workspace_bytes", "pcp_voxel_downsample", "pcp_sor_workspace_bytes", "pcp_statistical_outlier_removal",
 )
 
 
@@ -79,6 +80,14 @@ def load_library():
     L.pcp_fps_batched.restype = i32
     L.pcp_gather_rgb.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]; L.pcp_gather_rgb.restype = i32
     L.pcp_pack_dp3.argtypes = [vp, vp, i32, i32, vp, vp]; L.pcp_pack_dp3.restype = i32
+    f64 = C.c_double
+    L.pcp_voxel_workspace_bytes.argtypes = [i32, i64]; L.pcp_voxel_workspace_bytes.restype = sz
+    L.pcp_voxel_downsample.argtypes = [vp, vp, vp, i32, i64, f64, vp, vp, vp, vp, vp, i64, vp, vp, sz, vp]
+    L.pcp_voxel_downsample.restype = i32
+    L.pcp_sor_workspace_bytes.argtypes = [i32, i64]; L.pcp_sor_workspace_bytes.restype = sz
+    L.pcp_statistical_outlier_removal.argtypes = [vp, vp, vp, i32, i64, i32, f64, f64, vp, vp, vp, vp, vp, vp,
+                                                  i64, vp, vp, sz, vp]
+    L.pcp_statistical_outlier_removal.restype = i32
     _lib = L
     return L
 

@@ -211,6 +211,66 @@ def pack_dp3(xyz, rgb):
     return out
 
 
+def _csr_outputs(n, device, rgb, want_index=False):
+    out = dict(xyz64=torch.empty((n, 3), dtype=torch.float64, device=device),
+               xyz32=torch.empty((n, 3), dtype=torch.float32, device=device),
+               rgb32=torch.empty((n, 3), dtype=torch.float32, device=device) if rgb is not None else None)
+    if want_index:
+        out["index"] = torch.empty((n,), dtype=torch.int64, device=device)
+    return out
+
+
+def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None):
+    """Open3D-semantics voxel-grid mean filter on B CSR clouds (pcp_voxel_downsample).
+    xyz (n,3) f64, rgb (n,3) f32 or None, offsets (B+1) i64 → dict(xyz64, xyz32, rgb32, count), out_offsets."""
+    _require_cuda(xyz, offsets)
+    _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
+    if rgb is not None:
+        _chk(rgb, torch.float32, "rgb")
+    L = load_library()
+    B, dev = offsets.numel() - 1, xyz.device
+    n = int(xyz.shape[0] if cap_pts is None else cap_pts)
+    nb = L.pcp_voxel_workspace_bytes(B, n)
+    if nb == 0:
+        raise RuntimeError("pcp_voxel_workspace_bytes failed (no device?)")
+    ws = _workspace(nb, dev)
+    out = _csr_outputs(n, dev, rgb)
+    out["count"] = torch.empty((n,), dtype=torch.int32, device=dev)
+    out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.pcp_voxel_downsample(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, float(voxel_size), _ptr(out["xyz64"]),
+                                 _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["count"]), _ptr(out_off), n,
+                                 _ptr(ovf), _ptr(ws), nb, _stream()))
+    out["overflow"] = ovf
+    return out, out_off
+
+
+def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.0, cell_size=0.015, cap_pts=None):
+    """Open3D-semantics statistical outlier removal on B CSR clouds (pcp_statistical_outlier_removal).
+    → dict(xyz64, xyz32, rgb32, index, avg), out_offsets."""
+    _require_cuda(xyz, offsets)
+    _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
+    if rgb is not None:
+        _chk(rgb, torch.float32, "rgb")
+    L = load_library()
+    B, dev = offsets.numel() - 1, xyz.device
+    n = int(xyz.shape[0] if cap_pts is None else cap_pts)
+    nb = L.pcp_sor_workspace_bytes(B, n)
+    if nb == 0:
+        raise RuntimeError("pcp_sor_workspace_bytes failed (no device?)")
+    ws = _workspace(nb, dev)
+    out = _csr_outputs(n, dev, rgb, want_index=True)
+    out["avg"] = torch.zeros((n,), dtype=torch.float64, device=dev)
+    out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.pcp_statistical_outlier_removal(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, int(nb_neighbors),
+                                            float(std_ratio), float(cell_size), _ptr(out["xyz64"]),
+                                            _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["index"]),
+                                            _ptr(out_off), _ptr(out["avg"]), n, _ptr(ovf), _ptr(ws), nb, _stream()))
+    out["overflow"] = ovf
+    return out, out_off
+
+
 class FramePipeline:
     """The whole hot path for batches of B frames: depth+rgb → (B,K,3) xyz, (B,K,3) rgb,
     (B,K) idx.  All buffers are allocated once; run() only enqueues kernels."""

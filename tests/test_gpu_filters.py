@@ -1,0 +1,155 @@
+"""GPU (-m gpu): config-3 filters — voxel-grid downsample and statistical outlier removal — against the
+CPU restatements of Open3D's semantics in oracle/ (PARITY UNPINNED vs Open3D itself: it is absent and the
+reference tree holds no such filter; see oracle/pcp_oracle.c).  Bit-exact bar: FP64 means, f32 casts, masks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind, numpy_ref as R
+from helpers import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(clouds, cols=3, dtype=np.float64):
+    off = np.zeros(len(clouds) + 1, np.int64)
+    off[1:] = np.cumsum([len(c) for c in clouds])
+    flat = np.concatenate(clouds) if off[-1] else np.zeros((0, cols), dtype)
+    return flat.astype(dtype), off
+
+
+def _clouds(seed):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-0.3, 0.8, (5000, 3))
+    plane = np.c_[rng.uniform(0, 1, (4000, 2)), 0.2 + 0.002 * rng.standard_normal(4000)]
+    return [a, np.zeros((0, 3)), plane, np.array([[0.1, -0.2, 0.3]]), rng.uniform(0, 0.01, (300, 3)) - 5.0]
+
+
+@pytest.mark.parametrize("voxel,pad", [(0.05, 0), (0.005, 777), (1.0, 0)])
+def test_voxel_downsample_matches_oracle(voxel, pad):
+    from pcp import ops
+    clouds = _clouds(3)
+    rng = np.random.default_rng(4)
+    cols = [rng.random((len(c), 3)).astype(np.float32) for c in clouds]
+    xyz, off = _csr(clouds); rgb, _ = _csr(cols, dtype=np.float32)
+    n = len(xyz)
+    if pad:                                        # capacity rows beyond offsets[B] must be ignored
+        xyz = np.concatenate([xyz, np.full((pad, 3), 123.0)]); rgb = np.concatenate([rgb, np.ones((pad, 3), np.float32)])
+    out, out_off = ops.voxel_downsample(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(),
+                                        torch.from_numpy(off).cuda(), voxel)
+    assert int(out["overflow"].item()) == 0
+    oo = out_off.cpu().numpy()
+    for b, c in enumerate(clouds):
+        ref = cbind.voxel_downsample(c, cols[b], voxel)
+        lo, hi = oo[b], oo[b + 1]
+        assert hi - lo == len(ref["xyz64"]), f"cloud {b}"
+        np.testing.assert_array_equal(out["xyz64"][lo:hi].cpu().numpy(), ref["xyz64"])
+        np.testing.assert_array_equal(out["xyz32"][lo:hi].cpu().numpy(), ref["xyz32"])
+        np.testing.assert_array_equal(out["rgb32"][lo:hi].cpu().numpy(), ref["rgb32"])
+        np.testing.assert_array_equal(out["count"][lo:hi].cpu().numpy(), ref["count"])
+    assert int(out["count"][:oo[-1]].sum().item()) == n          # every point lands in exactly one voxel
+
+
+def test_voxel_downsample_no_colour_and_empty_batch():
+    from pcp import ops
+    xyz, off = _csr(_clouds(5)[:1])
+    out, out_off = ops.voxel_downsample(torch.from_numpy(xyz).cuda(), None, torch.from_numpy(off).cuda(), 0.02)
+    ref = cbind.voxel_downsample(xyz, None, 0.02)
+    assert out["rgb32"] is None
+    np.testing.assert_array_equal(out["xyz64"][:int(out_off[1])].cpu().numpy(), ref["xyz64"])
+    e, eo = ops.voxel_downsample(torch.zeros((0, 3), dtype=torch.float64).cuda(), None,
+                                 torch.zeros(3, dtype=torch.int64).cuda(), 0.02)
+    assert eo.cpu().tolist() == [0, 0, 0]
+
+
+def _sor_clouds(seed):
+    rng = np.random.default_rng(seed)
+    plane = np.c_[rng.uniform(0, 0.6, (3000, 2)), 0.2 + 0.001 * rng.standard_normal(3000)]
+    plane[::97] += rng.uniform(0.05, 0.4, (len(plane[::97]), 3))          # sprinkled outliers
+    blob = rng.normal(0, 0.03, (1500, 3)); blob[7] = [2.0, 2.0, -1.0]
+    dup = np.repeat(rng.uniform(0, 0.2, (40, 3)), 30, axis=0)             # 30 copies each → zero distances
+    return [plane, np.zeros((0, 3)), rng.uniform(0, 1, (5, 3)), blob, np.array([[1.0, 2.0, 3.0]]), dup]
+
+
+@pytest.mark.parametrize("nb,ratio,cell", [(20, 2.0, 0.02), (20, 2.0, 0.5), (20, 2.0, 0.002), (8, 1.0, 0.03), (32, 0.5, 0.05)])
+def test_statistical_outlier_removal_matches_oracle(nb, ratio, cell):
+    from pcp import ops
+    clouds = _sor_clouds(6)
+    rng = np.random.default_rng(7)
+    cols = [rng.random((len(c), 3)).astype(np.float32) for c in clouds]
+    xyz, off = _csr(clouds); rgb, _ = _csr(cols, dtype=np.float32)
+    out, out_off = ops.statistical_outlier_removal(torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(),
+                                                   torch.from_numpy(off).cuda(), nb, ratio, cell)
+    assert int(out["overflow"].item()) == 0
+    oo = out_off.cpu().numpy()
+    avg = out["avg"].cpu().numpy()
+    for b, c in enumerate(clouds):
+        ref = cbind.statistical_outlier(c, nb, ratio)
+        np.testing.assert_array_equal(avg[off[b]:off[b + 1]], ref["avg"], err_msg=f"cloud {b} avg")
+        lo, hi = oo[b], oo[b + 1]
+        assert hi - lo == ref["kept"], f"cloud {b}"
+        np.testing.assert_array_equal(out["index"][lo:hi].cpu().numpy(), np.nonzero(ref["keep"])[0])
+        np.testing.assert_array_equal(out["xyz64"][lo:hi].cpu().numpy(), c[ref["keep"]])
+        np.testing.assert_array_equal(out["xyz32"][lo:hi].cpu().numpy(), c[ref["keep"]].astype(np.float32))
+        np.testing.assert_array_equal(out["rgb32"][lo:hi].cpu().numpy(), cols[b][ref["keep"]])
+    assert 0 < oo[1] < 3000 and oo[5] - oo[4] == 0                        # outliers dropped; a lone point never survives
+
+
+def test_config3_pipeline_720p_voxel_sor_fps4096():
+    """BASELINE configs[2]: 1280x720 -> crop -> voxel -> SOR(20, 2.0) -> 4096-pt FPS.  Voxel 5 mm is checked
+    against the oracle in full; SOR at full size is checked on a 300-point sample of the per-point mean
+    distances (brute force), on the sequentially accumulated statistics, and on the mask they imply; the
+    coarse-voxel (2 cm) variant is checked against the brute-force oracle end to end, FPS included."""
+    from pcp import _ffi, ops
+    H, W = 720, 1280
+    intr = dict(fx=910.0, fy=910.0, cx=W / 2, cy=H / 2)
+    d, c = synth_frame(31, H, W)
+    s1 = ops.Stage1(1, H, W, torch.device("cuda"), want=("xyz64", "rgb32"))
+    out, off = s1.run(torch.from_numpy(d[None]).cuda(), torch.from_numpy(c[None]).cuda(),
+                      _ffi.make_params(intr, intr, apply_crop=True))
+    M = int(off[1].item())
+    ref1 = cbind.backproject_align_crop(d, c, cbind.make_params(intr, intr, apply_crop=1))
+    assert M == len(ref1["xyz64"]) and M > 100_000
+    xyz, rgb = out["xyz64"][:M].contiguous(), out["rgb32"][:M].contiguous()
+    for voxel, full in ((0.005, False), (0.02, True)):
+        v, voff = ops.voxel_downsample(xyz, rgb, off, voxel)
+        rv = cbind.voxel_downsample(ref1["xyz64"], ref1["rgb32"], voxel)
+        V = int(voff[1].item())
+        assert V == len(rv["xyz64"])
+        np.testing.assert_array_equal(v["xyz64"][:V].cpu().numpy(), rv["xyz64"])
+        np.testing.assert_array_equal(v["rgb32"][:V].cpu().numpy(), rv["rgb32"])
+        s, soff = ops.statistical_outlier_removal(v["xyz64"][:V].contiguous(), v["rgb32"][:V].contiguous(), voff,
+                                                  20, 2.0, 3 * voxel)
+        S = int(soff[1].item())
+        avg = s["avg"][:V].cpu().numpy()
+        if full:
+            rs = cbind.statistical_outlier(rv["xyz64"], 20, 2.0)
+            np.testing.assert_array_equal(avg, rs["avg"])
+            keep = rs["keep"]
+        else:
+            pick = np.random.default_rng(0).choice(V, 300, replace=False)
+            P = rv["xyz64"]
+            for i in pick:
+                dd = P[i] - P
+                d2 = np.sort(((dd[:, 0] * dd[:, 0]) + (dd[:, 1] * dd[:, 1])) + (dd[:, 2] * dd[:, 2]))[:20]
+                acc = 0.0
+                for t in np.sqrt(d2):
+                    acc = acc + t
+                assert avg[i] == acc / 20.0
+            mean = np.cumsum(avg)[-1] / V                                   # cumsum is strictly sequential
+            std = np.sqrt(np.cumsum((avg - mean) * (avg - mean))[-1] / (V - 1))
+            keep = (avg > 0) & (avg < mean + 2.0 * std)
+        assert S == int(keep.sum()) and 0.5 * V < S < V
+        np.testing.assert_array_equal(s["index"][:S].cpu().numpy(), np.nonzero(keep)[0])
+        np.testing.assert_array_equal(s["xyz32"][:S].cpu().numpy(), rv["xyz64"][keep].astype(np.float32))
+        K = 4096
+        fx, fi = ops.fps_batched(s["xyz32"][:S].contiguous(), soff, K)
+        col = ops.gather_rgb(s["rgb32"][:S].contiguous(), soff, fi)
+        if full:
+            r_xyz, r_idx = cbind.fps(rv["xyz64"][keep].astype(np.float32), K, 0)
+            np.testing.assert_array_equal(fi[0].cpu().numpy(), r_idx)
+            np.testing.assert_array_equal(fx[0].cpu().numpy(), r_xyz)
+            np.testing.assert_array_equal(col[0].cpu().numpy(), cbind.gather_rgb(rv["rgb32"][keep], r_idx, 1))
+        else:
+            idx = fi[0].cpu().numpy()
+            assert idx[0] == 0 and len(np.unique(idx)) == K and idx.max() < S

@@ -181,3 +181,30 @@ def test_pack_dp3_matches_chunking_restatement():
     rgb = (rng.integers(0, 256, (50, 3)) / 255.0).astype(np.float32)
     np.testing.assert_array_equal(cbind.pack_dp3(xyz, rgb), R.dp3_rows(xyz, rgb))
     np.testing.assert_array_equal(cbind.pack_dp3(xyz, rgb)[:, 3:], np.rint(rgb * 255))
+
+
+def test_voxel_downsample_c_equals_numpy_and_known_answer():
+    rng = np.random.default_rng(11)
+    xyz = rng.uniform(-0.2, 0.9, (4000, 3)); rgb = rng.random((4000, 3)).astype(np.float32)
+    a = cbind.voxel_downsample(xyz, rgb, 0.05)
+    b = R.voxel_downsample(xyz, rgb, 0.05)
+    np.testing.assert_array_equal(a["xyz64"], b[0]); np.testing.assert_array_equal(a["rgb32"], b[1])
+    np.testing.assert_array_equal(a["count"], b[2]); assert a["count"].sum() == 4000
+    # known answer: origin = min - 0.5 = (-0.5,..): points 0 and 1 share voxel 0, point 2 sits in voxel x=2
+    pts = np.array([[0.0, 0.0, 0.0], [0.4, 0.2, 0.1], [2.0, 0.0, 0.0]])
+    k = cbind.voxel_downsample(pts, None, 1.0)
+    np.testing.assert_array_equal(k["xyz64"], [[0.2, 0.1, 0.05], [2.0, 0.0, 0.0]])
+    np.testing.assert_array_equal(k["count"], [2, 1])
+    assert cbind.voxel_downsample(np.zeros((0, 3)), None, 0.1)["xyz64"].shape == (0, 3)
+
+
+def test_statistical_outlier_c_equals_numpy_and_flags_the_far_point():
+    rng = np.random.default_rng(12)
+    xyz = rng.normal(0, 0.05, (600, 3)); xyz[17] = [3.0, 3.0, 3.0]
+    a = cbind.statistical_outlier(xyz, 20, 2.0)
+    keep, avg, (mean, std, thr) = R.statistical_outlier(xyz, 20, 2.0)
+    np.testing.assert_array_equal(a["avg"], avg); np.testing.assert_array_equal(a["keep"], keep)
+    assert (a["mean"], a["std"], a["threshold"]) == (mean, std, thr)
+    assert not keep[17] and keep.sum() > 500
+    tiny = cbind.statistical_outlier(xyz[:5], 20, 2.0)              # M < nb: all points are each other's neighbours
+    np.testing.assert_array_equal(tiny["avg"], R.statistical_outlier(xyz[:5], 20, 2.0)[1])

@@ -238,6 +238,30 @@ def test_fps_ties_on_a_lattice(algo):
     np.testing.assert_array_equal(idx[0], ref_idx)
 
 
+def test_fps_cloud_shapes_cover_every_sort_plan():
+    """Cubic clouds sort along the 3-D Hilbert curve, flat ones along the 2-D curve over their two long axes
+    (any axis may be the thin one), the rest along the adaptive Morton order: all must give the oracle's picks."""
+    rng = np.random.default_rng(24)
+    n = 30000
+    u = lambda lo, hi: rng.uniform(lo, hi, n)
+    shapes = {
+        "cube": np.c_[u(0, 1), u(0, 1), u(0, 1)],
+        "flat_z": np.c_[u(0, 1), u(0, 0.9), 0.2 + 0.002 * rng.standard_normal(n)],
+        "flat_x": np.c_[0.001 * rng.standard_normal(n), u(-1, 1), u(0, 1.7)],
+        "flat_y": np.c_[u(0, 3), np.full(n, 0.25), u(0, 2.5)],
+        "slab_8_8_1": np.c_[u(0, 0.8), u(0, 0.8), u(0, 0.1)],
+        "rod": np.c_[u(0, 2), u(0, 0.05), u(0, 0.04)],
+        "line": np.c_[u(0, 1), np.zeros(n), np.zeros(n)],
+        "tabletop": np.c_[u(-0.05, 0.4), u(-0.12, 0.35), 0.02 + 0.002 * rng.standard_normal(n) + (rng.random(n) < 0.15) * u(0, 0.12)],
+    }
+    clouds = [v.astype(np.float32) for v in shapes.values()]
+    xyz, idx = run_fps(clouds, 512, 0, 2)
+    for b, (name, c) in enumerate(zip(shapes, clouds)):
+        ref_xyz, ref_idx = cbind.fps(c, 512, 0)
+        np.testing.assert_array_equal(idx[b], ref_idx, err_msg=name)
+        np.testing.assert_array_equal(xyz[b], ref_xyz, err_msg=name)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_fps_bench_frame_60k_points(algo):
     intr = bench_intr()

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=FRAMES, help="frames per episode (default 300)")
     ap.add_argument("--algo", type=int, default=0, help="FPS algorithm (0 auto, 1 brute, 2 bucket)")
+    ap.add_argument("--dist-mode", type=int, default=0, help="0: un-fused f32 distance (pytorch3d CPU build), 1: fused (CUDA build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="opt-in: stage 1 of step i+1 under the FPS of step i (2 streams, 2 buffer sets); +4 %% measured")
@@ -98,7 +99,7 @@ def main():
     # runs under the FPS rounds of step i (latency-bound, most of the chip idle).  Every step still
     # does all of its work; steps are only overlapped the way consecutive episodes would be.
     nbuf = 2 if args.overlap else 1
-    pipes = [ops.FramePipeline(B, H, W, K_FPS, params, dev, dist_mode=0, algo=args.algo) for _ in range(nbuf)]
+    pipes = [ops.FramePipeline(B, H, W, K_FPS, params, dev, dist_mode=args.dist_mode, algo=args.algo) for _ in range(nbuf)]
     s_front = torch.cuda.Stream(device=dev) if nbuf == 2 else torch.cuda.current_stream()
     s_back = torch.cuda.Stream(device=dev) if nbuf == 2 else torch.cuda.current_stream()
     ready = [torch.cuda.Event() for _ in range(nbuf)]       # stage-1 output of buffer set j is complete
@@ -176,7 +177,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: one synthetic {B}-frame episode per GPU, "
                                    f"640x480 depth+RGB -> crop -> {K_FPS}-pt FPS, resident in HBM",
                        "frames_per_step_per_gpu": B, "K": K_FPS, "mean_points_after_crop": m_mean,
-                       "fps_algo": args.algo, "dist_mode": "nofma",
+                       "fps_algo": args.algo, "dist_mode": "nofma" if args.dist_mode == 0 else "fma",
                        "step_overlap": "none" if not args.overlap else "stage 1 of step i+1 under FPS of step i (2 streams, 2 buffer sets)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],

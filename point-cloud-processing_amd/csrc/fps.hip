@@ -458,11 +458,10 @@ constexpr size_t fps_bucket_lds_bytes()
 }
 
 template <int T, int CPL, bool MULTI, int MODE>
-__global__ void __launch_bounds__(T, 2048 / T)           // two workgroups per CU: every frame of a 300-frame batch is resident
-__attribute__((amdgpu_num_sgpr(80)))                     // 8 waves/SIMD also need <= 80 SGPRs per wave (800 per SIMD, allocated 16 + 16k)
-fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
-           long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-           float* __restrict__ md, int m_lo, int m_hi)
+__device__ __forceinline__ void
+fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+                long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                float* __restrict__ md, int m_lo, int m_hi)
 {
     // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
     constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
@@ -698,6 +697,28 @@ fps_bucket(const float* __restrict__ xyz, const long long* __restrict__ offsets,
 #endif
 }
 
+// "wide" shape (single-chunk buckets): two workgroups of 1024 (four of 512) per CU, so every frame of a
+// 300-frame batch is resident at once.  8 waves/SIMD need <= 64 VGPRs and <= 80 SGPRs per wave (800 per
+// SIMD, allocated 16 + 16k); the caps are explicit because __launch_bounds__ alone does not enforce them.
+template <int T, int CPL, int MODE>
+__global__ void __launch_bounds__(T, 2048 / T) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
+fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+                long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                float* __restrict__ md, int m_lo, int m_hi)
+{
+    fps_bucket_body<T, CPL, false, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
+}
+
+// "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
+template <int T, int CPL, int MODE>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
+fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+                long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                float* __restrict__ md, int m_lo, int m_hi)
+{
+    fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
+}
+
 // ---- host entry points -------------------------------------------------------------------------
 static int fps_pick_algo(int algo, int64_t max_pts)
 {
@@ -723,7 +744,9 @@ static int launch_bucket_as(const float* xyz, const long long* offsets, int B, i
                             float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, hipStream_t st)
 {
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
-    auto kern = fps_bucket<T, CPL, MULTI, MODE>;
+    void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int);
+    if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
+    else kern = fps_bucket_wide<T, CPL, MODE>;
     if (lds > 48 * 1024)
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);

@@ -10,8 +10,8 @@
 // strategy (grid here, kd-tree in Open3D, brute force in the tests) cannot change the result.
 //
 // Pipeline: uniform grid of `cell` metres keyed like the voxel filter (cloud | ix | iy | iz), stable
-// radix sort, points gathered into sorted order; one thread per sorted point scans the x-slabs of the
-// (2r+1)^3 neighbourhood for r = 1..3 until the k-th distance is provably inside the scanned block,
+// radix sort, points gathered into sorted order; one thread per sorted point scans the (x,y) rows of the
+// (2r+1)^3 neighbourhood (each row is one contiguous key run) for r = 1..3 until the k-th distance is provably inside the scanned block,
 // else falls back to the whole cloud; one wave per cloud does the sequential statistics; the keep
 // flags are compacted with the ballot / tile-scan machinery.
 #include "pcp_internal.h"
@@ -84,18 +84,18 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
         for (int r = 1; r <= SOR_RMAX && !done; ++r) {
 #pragma unroll
             for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
-            const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > 65535 ? 65535 : cy + r;
+            const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > 65535 ? 65535 : cz + r;
             for (int x = cx - r; x <= cx + r; ++x) {
                 if (x < 0 || x > 65535) continue;
-                const unsigned long long k0 = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y0 << 16);
-                const unsigned long long k1 = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y1 << 16) | 0xFFFFull;
-                for (long long t = sor_lower_bound(keys, lo, hi, k0); t < hi; ++t) {
-                    const unsigned long long kt = keys[t];
-                    if (kt > k1) break;
-                    const int dzc = (int)(kt & 0xFFFF) - cz;
-                    if (dzc > r || dzc < -r) continue;
-                    const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
-                    sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+                for (int y = cy - r; y <= cy + r; ++y) {                 // one contiguous key run per (x,y) row
+                    if (y < 0 || y > 65535) continue;
+                    const unsigned long long row = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y << 16);
+                    const unsigned long long k1 = row | (unsigned long long)z1;
+                    for (long long t = sor_lower_bound(keys, lo, hi, row | (unsigned long long)z0); t < hi; ++t) {
+                        if (keys[t] > k1) break;
+                        const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
+                        sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+                    }
                 }
             }
             const double lim = ((double)r * cell) * (1.0 - 1e-9);      // every point closer than this was scanned
@@ -117,8 +117,18 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
     avg[vals[j]] = s / (double)k;
 }
 
-// One wave per cloud: strictly sequential sums (point order), as std::accumulate does.
-// stats[b] = {mean, std, threshold, 0}
+// One wave per cloud: strictly sequential sums (point order), as std::accumulate does.  The lanes load 64
+// values at a time and turn them into the addends in parallel (0.0 for a skipped value: adding +0.0 to
+// a non-negative running sum is exact), so the serial chain is one v_add_f64 per point with the addend
+// read from a lane into scalar registers.   stats[b] = {mean, std, threshold, 0}
+__device__ __forceinline__ double sor_lane_f64(double v, int t)
+{
+    const long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, t);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), t);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __global__ void __launch_bounds__(64)
 sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets, double std_ratio,
           double* __restrict__ stats)
@@ -132,15 +142,14 @@ sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets,
         double acc = 0.0;
         double nxt = lo + lane < hi ? avg[lo + lane] : 0.0;
         for (long long base = lo; base < hi; base += 64) {
-            const double v = nxt;
+            const double y = nxt;
             const long long ni = base + 64 + lane;
             nxt = ni < hi ? avg[ni] : 0.0;                            // prefetch under the serial chain
+            double term;
+            if (pass == 0) term = y > 0.0 ? y : 0.0;
+            else term = y > 0.0 ? (y - mean) * (y - mean) : 0.0;
 #pragma unroll
-            for (int t = 0; t < 64; ++t) {
-                const double y = __shfl(v, t, 64);
-                if (pass == 0) acc = y > 0.0 ? acc + y : acc;
-                else acc = y > 0.0 ? acc + (y - mean) * (y - mean) : acc;
-            }
+            for (int t = 0; t < 64; ++t) acc = acc + sor_lane_f64(term, t);
         }
         res[pass] = acc;
         if (pass == 0) mean = acc / (double)M;
@@ -272,7 +281,7 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
     const int tiles = (int)((cap_pts + PCP_TILE - 1) / PCP_TILE);
 
     PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
-    hipLaunchKernelGGL(vox_minbound, dim3(nblk), dim3(256), 0, st, xyz, off, B, minb);
+    hipLaunchKernelGGL(vox_minbound, dim3((nblk + VOX_MB_ITERS - 1) / VOX_MB_ITERS), dim3(256), 0, st, xyz, off, B, minb);
     hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, cell_size,
                        keys_in, vals_in, overflow);
     size_t temp_bytes = L.v.temp_bytes;

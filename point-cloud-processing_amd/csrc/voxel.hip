@@ -46,37 +46,57 @@ __device__ __forceinline__ int vox_cloud_of(const long long* __restrict__ offset
     return lo;
 }
 
+// Each block walks VOX_MB_ITERS*256 consecutive rows; a wave keeps a running min while the rows stay in one
+// cloud and flushes it with three atomics only when the cloud changes or the walk ends.
+#define VOX_MB_ITERS 16
 __global__ void __launch_bounds__(256)
 vox_minbound(const double* __restrict__ xyz, const long long* __restrict__ offsets, int B,
              unsigned long long* __restrict__ minb)
 {
     const long long n = offsets[B];
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    const long long ic = live ? i : (n > 0 ? n - 1 : 0);
-    int b = 0;
-    double p[3] = {0.0, 0.0, 0.0};
-    if (n > 0) {
-        b = vox_cloud_of(offsets, B, ic);
-        p[0] = xyz[3 * ic]; p[1] = xyz[3 * ic + 1]; p[2] = xyz[3 * ic + 2];
-    }
-    if (n <= 0) return;
-    const int b0 = __builtin_amdgcn_readfirstlane(b);
-    if (__all(b == b0)) {                      // the usual case: one cloud per wave → 3 atomics per wave
+    const int lane = pcp_lane();
+    const long long first = (long long)blockIdx.x * (256 * VOX_MB_ITERS) + (threadIdx.x >> 6) * (64 * VOX_MB_ITERS);
+    if (first >= n) return;
+    int cur = -1;                                  // wave-uniform cloud of the running min
+    double m[3] = {0.0, 0.0, 0.0};
+    auto flush = [&]() {
+        if (cur < 0) return;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            double v = p[c];
+            double v = m[c];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 const double o = __shfl_xor(v, d, 64);
                 v = o < v ? o : v;
             }
-            if (pcp_lane() == 0) atomicMin(&minb[3 * b0 + c], vox_ord(v));
+            if (lane == 0) atomicMin(&minb[3 * cur + c], vox_ord(v));
         }
-    } else if (live) {
+    };
+    for (int it = 0; it < VOX_MB_ITERS; ++it) {
+        const long long i0 = first + (long long)it * 64;
+        if (i0 >= n) break;                        // wave-uniform
+        const long long i = i0 + lane < n ? i0 + lane : n - 1;            // clamped duplicate: harmless for a min
+        const int b = vox_cloud_of(offsets, B, i);
+        const double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        const int b0 = __builtin_amdgcn_readfirstlane(b);
+        if (__all(b == b0)) {
+            if (b0 != cur) {
+                flush();
+                cur = b0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicMin(&minb[3 * b + c], vox_ord(p[c]));
+                for (int c = 0; c < 3; ++c) m[c] = p[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) m[c] = p[c] < m[c] ? p[c] : m[c];
+            }
+        } else {                                   // a cloud boundary inside these 64 rows: per-lane atomics
+            flush();
+            cur = -1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) atomicMin(&minb[3 * b + c], vox_ord(p[c]));
+        }
     }
+    flush();
 }
 
 __global__ void __launch_bounds__(256)
@@ -268,7 +288,7 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
     const int tiles = (int)((cap_pts + PCP_TILE - 1) / PCP_TILE);
 
     PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
-    hipLaunchKernelGGL(vox_minbound, dim3(nblk), dim3(256), 0, st, xyz, off, B, minb);
+    hipLaunchKernelGGL(vox_minbound, dim3((nblk + VOX_MB_ITERS - 1) / VOX_MB_ITERS), dim3(256), 0, st, xyz, off, B, minb);
     hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, voxel_size,
                        keys_in, vals_in, overflow);
     size_t temp_bytes = L.temp_bytes;

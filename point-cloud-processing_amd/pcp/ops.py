@@ -245,9 +245,24 @@ def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None):
     return out, out_off
 
 
-def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.0, cell_size=0.015, cap_pts=None):
+def sor_cell_size(xyz, n_clouds, nb_neighbors=20):
+    """Search-grid edge for statistical_outlier_removal: the radius that holds ~nb_neighbors points at the
+    batch's mean density (bounding-box volume / points per cloud), with 30 % head-room so that the first
+    ring of cells almost always proves the k-th neighbour.  Only speed depends on it.  Synchronises."""
+    n = xyz.shape[0]
+    if n == 0 or n_clouds == 0:
+        return 1.0
+    ext = (xyz.amax(0) - xyz.amin(0)).cpu().numpy().astype(float)
+    ext = [max(e, 1e-6) for e in ext]
+    per_cloud = max(n / n_clouds, 1.0)
+    vol = ext[0] * ext[1] * ext[2]
+    cell = 1.3 * (3.0 * nb_neighbors * vol / (4.0 * 3.141592653589793 * per_cloud)) ** (1.0 / 3.0)
+    return max(cell, max(ext) / 60000.0)          # keep every grid index inside 16 bits
+
+
+def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.0, cell_size=None, cap_pts=None):
     """Open3D-semantics statistical outlier removal on B CSR clouds (pcp_statistical_outlier_removal).
-    → dict(xyz64, xyz32, rgb32, index, avg), out_offsets."""
+    cell_size None → sor_cell_size().  → dict(xyz64, xyz32, rgb32, index, avg), out_offsets."""
     _require_cuda(xyz, offsets)
     _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
     if rgb is not None:
@@ -255,6 +270,8 @@ def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.
     L = load_library()
     B, dev = offsets.numel() - 1, xyz.device
     n = int(xyz.shape[0] if cap_pts is None else cap_pts)
+    if cell_size is None:
+        cell_size = sor_cell_size(xyz[:n], B, nb_neighbors)
     nb = L.pcp_sor_workspace_bytes(B, n)
     if nb == 0:
         raise RuntimeError("pcp_sor_workspace_bytes failed (no device?)")

@@ -71,7 +71,7 @@ def _sor_clouds(seed):
     return [plane, np.zeros((0, 3)), rng.uniform(0, 1, (5, 3)), blob, np.array([[1.0, 2.0, 3.0]]), dup]
 
 
-@pytest.mark.parametrize("nb,ratio,cell", [(20, 2.0, 0.02), (20, 2.0, 0.5), (20, 2.0, 0.002), (8, 1.0, 0.03), (32, 0.5, 0.05)])
+@pytest.mark.parametrize("nb,ratio,cell", [(20, 2.0, None), (20, 2.0, 0.02), (20, 2.0, 0.5), (20, 2.0, 0.002), (8, 1.0, 0.03), (32, 0.5, 0.05)])
 def test_statistical_outlier_removal_matches_oracle(nb, ratio, cell):
     from pcp import ops
     clouds = _sor_clouds(6)

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Secondary timings (not the headline metric) for BASELINE configs[2] and configs[4] on one MI355X:
+   config 3: 1280x720 depth -> crop -> voxel 5 mm -> SOR(20, 2.0) -> 4096-pt FPS
+   config 5: 4 cameras x 640x480 fused per frame -> 8192-pt FPS
+Prints one JSON line per config with per-stage HIP-event times.   python3 tools/bench_configs.py [--frames N]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]
+import numpy as np, torch
+from pcp import _ffi, ops, synth
+
+
+def timed(stages, reps=3):
+    ev = {k: [] for k, _ in stages}
+    for r in range(reps + 1):
+        for name, fn in stages:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            if r:
+                ev[name].append(a.elapsed_time(b))
+    return {k: round(float(np.mean(v)), 3) for k, v in ev.items()}
+
+
+def config3(B):
+    H, W, K = 720, 1280, 4096
+    intr = synth.intrinsics(H, W, f=910.0)
+    p = _ffi.make_params(intr, intr, apply_crop=True)
+    d, c = synth.episode(B, seed0=0, H=H, W=W)
+    depth, rgb = torch.from_numpy(d).cuda(), torch.from_numpy(c).cuda()
+    s1 = ops.Stage1(B, H, W, depth.device, want=("xyz64", "rgb32"))
+    st = {}
+    def f1(): st["o"], st["off"] = s1.run(depth, rgb, p)
+    f1(); M = int(st["off"][-1].item())
+    def f2(): st["v"], st["voff"] = ops.voxel_downsample(st["o"]["xyz64"], st["o"]["rgb32"], st["off"], 0.005, cap_pts=M)
+    f2(); V = int(st["voff"][-1].item())
+    st["cell"] = ops.sor_cell_size(st["v"]["xyz64"][:V], B, 20)
+    def f3(): st["s"], st["soff"] = ops.statistical_outlier_removal(st["v"]["xyz64"], st["v"]["rgb32"], st["voff"], 20, 2.0, st["cell"], cap_pts=V)
+    f3(); S = int(st["soff"][-1].item())
+    mx = int((st["soff"][1:] - st["soff"][:-1]).max().item())
+    plan = ops.Fps(B, S, mx, K, depth.device)
+    def f4():
+        st["fx"], st["fi"] = plan.run(st["s"]["xyz32"][:S], st["soff"])
+        st["col"] = ops.gather_rgb(st["s"]["rgb32"][:S], st["soff"], st["fi"])
+    t = timed([("stage1_crop", f1), ("voxel_5mm", f2), ("sor_20_2.0", f3), ("fps_4096+gather", f4)])
+    tot = sum(t.values())
+    return {"config": "3: 1280x720 -> crop -> voxel 5 mm -> SOR(20,2.0) -> 4096-pt FPS", "frames": B, "ms": t, "ms_total": round(tot, 3),
+            "frames_per_s": round(B / tot * 1e3, 1), "sor_cell_m": round(st["cell"], 4), "points_per_frame": {"cropped": M // B, "voxels": V // B, "inliers": S // B}}
+
+
+def config5(F):
+    H, W, K, C = 480, 640, 8192, 4
+    intr = synth.intrinsics(H, W)
+    base = np.asarray(_ffi.default_params().ext, dtype=np.float64).reshape(4, 4)
+    cams = []
+    for c in range(C):
+        th = np.deg2rad(7.0 * c)
+        Rz = np.array([[np.cos(th), -np.sin(th), 0, 0.02 * c], [np.sin(th), np.cos(th), 0, -0.03 * c], [0, 0, 1, 0.01 * c], [0, 0, 0, 1]])
+        cams.append(_ffi.make_params(intr, intr, ext=Rz @ base, apply_crop=True))
+    d, c = synth.episode(F * C, seed0=0, H=H, W=W)
+    depth = torch.from_numpy(d.reshape(F, C, H, W)).cuda(); rgb = torch.from_numpy(c.reshape(F, C, H, W, 3)).cuda()
+    s1 = ops.Stage1MultiCam(F, C, H, W, depth.device)
+    st = {}
+    def f1(): st["o"], st["foff"], _ = s1.run(depth, rgb, cams)
+    f1(); tot_pts = int(st["foff"][-1].item()); mx = int((st["foff"][1:] - st["foff"][:-1]).max().item())
+    plan = ops.Fps(F, tot_pts, mx, K, depth.device)
+    def f2():
+        st["fx"], st["fi"] = plan.run(st["o"]["xyz32"][:tot_pts], st["foff"])
+        st["col"] = ops.gather_rgb(st["o"]["rgb32"][:tot_pts], st["foff"], st["fi"])
+    t = timed([("stage1_multicam_crop", f1), ("fps_8192+gather", f2)])
+    tot = sum(t.values())
+    return {"config": "5: 4 cameras x 640x480 fused -> 8192-pt FPS", "fused_frames": F, "ms": t, "ms_total": round(tot, 3),
+            "fused_frames_per_s": round(F / tot * 1e3, 1), "points_per_fused_frame": tot_pts // F}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    a = ap.parse_args()
+    print(json.dumps(config3(a.frames)), flush=True)
+    print(json.dumps(config5(a.frames)), flush=True)

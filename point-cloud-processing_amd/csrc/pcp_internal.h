@@ -85,6 +85,17 @@ __device__ __forceinline__ int pcp_block_excl_scan(int v, int* lds, int* total)
     return out;
 }
 
+// (i / W, i % W) for 0 <= i < 2^31 and i / W < 2^20 without the ~40-instruction integer division: a float estimate of
+// the quotient (off by at most one in that range) and an exact integer fix-up.
+__device__ __forceinline__ void pcp_divmod(int i, int W, float invW, int* q, int* r)
+{
+    int v = (int)((float)i * invW);
+    int u = i - v * W;
+    if (u < 0) { v -= 1; u += W; }
+    else if (u >= W) { v += 1; u -= W; }
+    *q = v; *r = u;
+}
+
 // position (0..63) of the n-th (0-based) set bit of m; m must have more than n bits set
 __device__ __forceinline__ int pcp_select_bit(unsigned long long m, int n)
 {

@@ -117,7 +117,9 @@ k1_dense(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
     const size_t g = (size_t)b * HW + i;
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
     PixelOut o;
-    pixel_math<true>(P, depth[g], i % W, i / W, img, Hc, Wc, o);
+    int pv, pu;
+    pcp_divmod(i, W, 1.0f / (float)W, &pv, &pu);
+    pixel_math<true>(P, depth[g], pu, pv, img, Hc, Wc, o);
     if (pts_cam) { pts_cam[3 * g] = o.cam[0]; pts_cam[3 * g + 1] = o.cam[1]; pts_cam[3 * g + 2] = o.cam[2]; }
     if (pts_base) { pts_base[3 * g] = o.base[0]; pts_base[3 * g + 1] = o.base[1]; pts_base[3 * g + 2] = o.base[2]; }
     if (colors) { colors[3 * g] = o.col[0]; colors[3 * g + 1] = o.col[1]; colors[3 * g + 2] = o.col[2]; }
@@ -141,6 +143,7 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
     unsigned long long* mrow = masks + ((size_t)b * tiles + tile) * PCP_TILE_WORDS;
     int cnt = 0;
+    const float invW = 1.0f / (float)W;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int word = wave * 4 + r;
@@ -148,7 +151,9 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
         int keep = 0;
         if (i < HW) {
             PixelOut o;
-            pixel_math<false>(P, dframe[i], i % W, i / W, img, Hc, Wc, o);
+            int pv, pu;
+            pcp_divmod(i, W, invW, &pv, &pu);
+            pixel_math<false>(P, dframe[i], pu, pv, img, Hc, Wc, o);
             keep = o.keep;
         }
         const unsigned long long m = __ballot(keep);
@@ -246,7 +251,9 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
         const long long row = base + j;
         if (row >= cap) { if (overflow) *overflow = 1; continue; }
         PixelOut o;
-        pixel_math<true>(P, dframe[i], i % W, i / W, img, Hc, Wc, o);
+        int pv, pu;
+        pcp_divmod(i, W, 1.0f / (float)W, &pv, &pu);
+        pixel_math<true>(P, dframe[i], pu, pv, img, Hc, Wc, o);
         if (xyz_cam64) { xyz_cam64[3 * row] = o.cam[0]; xyz_cam64[3 * row + 1] = o.cam[1]; xyz_cam64[3 * row + 2] = o.cam[2]; }
         if (xyz64) { xyz64[3 * row] = o.base[0]; xyz64[3 * row + 1] = o.base[1]; xyz64[3 * row + 2] = o.base[2]; }
         if (xyz32) { xyz32[3 * row] = (float)o.base[0]; xyz32[3 * row + 1] = (float)o.base[1]; xyz32[3 * row + 2] = (float)o.base[2]; }   // DP3:10
@@ -285,7 +292,7 @@ extern "C" int pcp_backproject_dense(const float* depth, const uint8_t* rgb, int
 {
     if (!depth || !params_ok(p) || B < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0)
         return PCP_ERR_INVALID_ARG;
-    if ((long long)H * W > 0x7fffffffLL / 4) return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4 || H >= (1 << 20)) return PCP_ERR_INVALID_ARG;
     if (B == 0) return PCP_OK;
     const int HW = H * W;
     dim3 grid((HW + 255) / 256, B);
@@ -317,7 +324,7 @@ static int backproject_align_crop_impl(const float* depth, const uint8_t* rgb, i
     for (int c = 0; c < C; ++c)
         if (!params_ok(cams + c)) return PCP_ERR_INVALID_ARG;
     if (rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
-    if ((long long)H * W > 0x7fffffffLL / 4 || (long long)F * C > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4 || H >= (1 << 20) || (long long)F * C > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     const int B = F * C;
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_backproject_workspace_bytes(B, H, W))
         return PCP_ERR_WORKSPACE;

@@ -43,45 +43,78 @@ def rows_from_filtered_ply(traj_pc_path, state_indices):
     return out
 
 
+def _count_states(extracted):
+    with open(os.path.join(extracted, "states.txt")) as fh:
+        return sum(1 for line in fh if line.strip())
+
+
+def _process_traj(data_root, traj, source, K, frame_skip, intr, ext, runner_box):
+    """One trajectory → (rows list, action, state) or None when it is skipped (CHK:67-70, 127-132)."""
+    extracted = os.path.join(data_root, traj, "extracted_data", traj)
+    pc_path = os.path.join(data_root, traj, "filtered_point_clouds")
+    state, action, s_idx = load_states_actions(extracted, frame_skip)
+    if source == "ply":
+        rows = rows_from_filtered_ply(pc_path, s_idx)
+    else:
+        from pcp import _ffi, extract_point_clouds_one_cam as xpc
+        from pcp.episode import EpisodeRunner
+        intr_t = intr or xpc.extract_intrinsics(extracted, extracted)
+        d0 = np.load(os.path.join(extracted, "camera", "depth", "depth_00000.npy"))
+        runner = runner_box.get("runner")
+        if runner is None or (runner.H, runner.W) != d0.shape:
+            p = _ffi.make_params(intr_t["depth"], intr_t["color"], T=xpc.T_DEPTH_TO_COLOR, ext=ext, apply_crop=True)
+            runner = runner_box["runner"] = EpisodeRunner(d0.shape[0], d0.shape[1], K, p, device=runner_box.get("device", "cuda"))
+        all_rows, _, ids = runner.run_tree(extracted)
+        rows = [all_rows[i] for i in s_idx if i < len(all_rows)]
+    if len(rows) != state.shape[0]:
+        print(f"Warning: {traj} has {state.shape[0]} states but {len(rows)} point clouds. Skipping.")   # CHK:127-132
+        return None
+    return rows, action, state
+
+
 def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, compressor="zlib", intr=None,
           ext=None):
     """source='ply': read <traj>/filtered_point_clouds (the reference's route).
-    source='gpu': run depth+rgb of <traj>/extracted_data/<traj> through the GPU path directly."""
-    pcs, actions, states, ends, total = [], [], [], [], 0
-    runner = None
+    source='gpu': run depth+rgb of <traj>/extracted_data/<traj> through the GPU path directly.
+    Under torch.distributed (one process per GPU, BASELINE configs[3]) whole trajectories are dealt to the
+    ranks longest-first, every rank processes its own on its own GPU, the blocks are gathered host-side in
+    sorted-trajectory order and rank 0 writes the store — `episode_ends` equals the single-process run's."""
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    trajs = []
     for traj in sorted(d for d in os.listdir(data_root) if os.path.isdir(os.path.join(data_root, d))):
         extracted = os.path.join(data_root, traj, "extracted_data", traj)
         need = [os.path.join(extracted, "states.txt"), os.path.join(extracted, "actions.txt"),
                 os.path.join(extracted, "camera", "rgb")]
-        pc_path = os.path.join(data_root, traj, "filtered_point_clouds")
         if source == "ply":
-            need.append(pc_path)
+            need.append(os.path.join(data_root, traj, "filtered_point_clouds"))
         if not all(os.path.exists(p) for p in need):
-            print(f"Skipping {traj}: Missing one or more data components.")            # CHK:67-70
+            if rank == 0:
+                print(f"Skipping {traj}: Missing one or more data components.")        # CHK:67-70
             continue
-        state, action, s_idx = load_states_actions(extracted, frame_skip)
-        if source == "ply":
-            rows = rows_from_filtered_ply(pc_path, s_idx)
-        else:
-            from pcp import _ffi, extract_point_clouds_one_cam as xpc
-            from pcp.episode import EpisodeRunner
-            intr_t = intr or xpc.extract_intrinsics(extracted, extracted)
-            d0 = np.load(os.path.join(extracted, "camera", "depth", "depth_00000.npy"))
-            if runner is None or (runner.H, runner.W) != d0.shape:
-                p = _ffi.make_params(intr_t["depth"], intr_t["color"], T=xpc.T_DEPTH_TO_COLOR, ext=ext, apply_crop=True)
-                runner = EpisodeRunner(d0.shape[0], d0.shape[1], K, p)
-            all_rows, _, ids = runner.run_tree(extracted)
-            rows = [all_rows[i] for i in s_idx if i < len(all_rows)]
-        if len(rows) != state.shape[0]:
-            print(f"Warning: {traj} has {state.shape[0]} states but {len(rows)} point clouds. Skipping.")   # CHK:127-132
+        trajs.append(traj)
+    from pcp import shard
+    mine = shard.assign_episodes([_count_states(os.path.join(data_root, t, "extracted_data", t)) for t in trajs], world)[rank]
+    runner_box = {"device": f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"}
+    local = {i: _process_traj(data_root, trajs[i], source, K, frame_skip, intr, ext, runner_box) for i in mine}
+    results = shard.gather_episodes(local, len(trajs))
+    pcs, actions, states, ends, total = [], [], [], [], 0
+    for res in results:
+        if res is None:
             continue
+        rows, action, state = res
         pcs.extend(rows); actions.append(action); states.append(state)
         total += state.shape[0]
         ends.append(total)                                                           # CHK:151-152
     if not pcs:
         raise RuntimeError("no complete trajectory found")
-    zarr_store.write_dp3_dataset(out_zarr, np.stack(pcs, axis=0), np.vstack(actions), np.vstack(states),
-                                 np.array(ends, dtype=np.int64), CHUNK_SIZE, compressor)
+    if rank == 0:
+        zarr_store.write_dp3_dataset(out_zarr, np.stack(pcs, axis=0), np.vstack(actions), np.vstack(states),
+                                     np.array(ends, dtype=np.int64), CHUNK_SIZE, compressor)
+    if distributed:
+        dist.barrier()
     return total, len(ends)
 
 
@@ -92,8 +125,15 @@ def main():
     ap.add_argument("--source", choices=("ply", "gpu"), default="ply")
     ap.add_argument("--num_points", type=int, default=2500)
     a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:                                   # launched by torch.distributed.run: one process per GPU
+        import torch.distributed as dist
+        dist.init_process_group("gloo")             # host-side object gather only; no data-path collective
     n, e = build(a.data_root, a.out_zarr, a.source, a.num_points)
-    print(f"Saved Zarr file: {a.out_zarr}  ({n} frames, {e} episodes)")
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"Saved Zarr file: {a.out_zarr}  ({n} frames, {e} episodes)")
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

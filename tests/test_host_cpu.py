@@ -155,3 +155,40 @@ def test_states_actions_frame_skip_and_gripper(tmp_path):
     assert a[:, 6].tolist() == [1.0, 1.0, 0.0]                          # /30 clipped to [-1,1] (CHK:103)
     s1, a1, _ = build_zarr.load_states_actions(str(tmp_path), frame_skip=1)
     assert a1[:, 6].tolist() == [-1, 0, 1, 1, -1, 0.5, 0, 1, -1, 0]
+
+
+def _make_ply_dataset(root, lens, K=16):
+    rng = np.random.default_rng(5)
+    for b, n in enumerate(lens):
+        name = f"traj{b:02d}"
+        ext = os.path.join(root, name, "extracted_data", name)
+        os.makedirs(os.path.join(ext, "camera", "rgb"))
+        pcd = os.path.join(root, name, "filtered_point_clouds"); os.makedirs(pcd)
+        st = rng.normal(size=(n, 7)); ac = rng.normal(size=(n, 7)) * 20
+        np.savetxt(os.path.join(ext, "states.txt"), st); np.savetxt(os.path.join(ext, "actions.txt"), ac)
+        for i in range(n if b != 2 else n - 1):                           # traj02 misses one cloud → skipped (CHK:127-132)
+            ply.write_point_cloud(os.path.join(pcd, f"pc_{i:05d}_filtered.ply"), rng.normal(size=(K, 3)),
+                                  rng.integers(0, 256, (K, 3)) / 255.0)
+
+
+def test_build_zarr_ply_route_single_and_two_rank_gloo_agree(tmp_path):
+    """BASELINE configs[3] host logic: trajectories dealt to ranks, gathered in order, rank 0 writes; the
+    store must equal the single-process one (episode_ends included)."""
+    from pcp import build_zarr, zarr_store
+    root = str(tmp_path / "data"); lens = [6, 3, 4, 5]
+    _make_ply_dataset(root, lens)
+    n, e = build_zarr.build(root, str(tmp_path / "one.zarr"), source="ply")
+    assert (n, e) == (14, 3)
+    one = zarr_store.read_dp3_dataset(str(tmp_path / "one.zarr"))
+    assert one["episode_ends"].tolist() == [6, 9, 14] and one["point_cloud"].shape == (14, 16, 6)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() + 7) % 2000), WORLD_SIZE="2")
+    script = os.path.join(ROOT, "point-cloud-processing_amd", "pcp", "build_zarr.py")
+    procs = [subprocess.Popen([sys.executable, script, "--data_root", root, "--out_zarr", str(tmp_path / "two.zarr")],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    two = zarr_store.read_dp3_dataset(str(tmp_path / "two.zarr"))
+    for k in one:
+        np.testing.assert_array_equal(one[k], two[k])

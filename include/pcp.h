@@ -111,6 +111,14 @@ int pcp_align_colors(const double* pts, int64_t n, const uint8_t* rgb, int Hc, i
 size_t pcp_backproject_workspace_bytes(int B, int H, int W);
 
 /*
+ * Raw 16-bit depth in millimetres → metres, the conversion the extraction step applies before it
+ * stores depth_%05d.npy (extract_topics_one_camera.py:68-72: astype(float32) / 1000.0, one f32
+ * division).  Lets a caller upload half the bytes and keep the rest of the path unchanged.
+ *   depth_mm (n) u16 → depth_m (n) f32
+ */
+int pcp_depth_mm_to_m(const uint16_t* depth_mm, int64_t n, float* depth_m, void* stream);
+
+/*
  * Fused backproject + colour-align + validity (+ crop) + order-preserving
  * compaction for B frames.  Surviving points keep row-major pixel order
  * (numpy boolean-mask order, XPC:110 / DP3:41), frames are concatenated CSR

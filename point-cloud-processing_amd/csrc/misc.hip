@@ -38,6 +38,24 @@ pack_dp3_k(const float* __restrict__ xyz, const float* __restrict__ rgb, long lo
     }
 }
 
+// extract_topics_one_camera.py:72 (XTP): depth = depth_u16.astype(np.float32) / 1000.0 — one f32 division
+__global__ void __launch_bounds__(256)
+depth_mm_k(const uint16_t* __restrict__ mm, long long n, float* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)mm[i] / 1000.0f;
+}
+
+extern "C" int pcp_depth_mm_to_m(const uint16_t* depth_mm, int64_t n, float* depth_m, void* stream)
+{
+    if (n < 0) return PCP_ERR_INVALID_ARG;
+    if (n == 0) return PCP_OK;
+    if (!depth_mm || !depth_m) return PCP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(depth_mm_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       depth_mm, (long long)n, depth_m);
+    return pcp_launch_status();
+}
+
 extern "C" int pcp_gather_rgb(const float* rgb, const int64_t* offsets, const int64_t* idx, int B,
                               int K, int compat_neg_index, float* out, void* stream)
 {

@@ -9,7 +9,7 @@ _LIB = os.path.normpath(os.path.join(_HERE, "..", "lib", "libpcp_hip.so"))
 EXPORTS = (
     "pcp_default_params", "pcp_strerror", "pcp_version", "pcp_device_count",
     "pcp_backproject_dense", "pcp_align_colors", "pcp_backproject_workspace_bytes", "pcp_backproject_align_crop",
-    "pcp_backproject_align_crop_multicam",
+    "pcp_backproject_align_crop_multicam", "pcp_depth_mm_to_m",
     "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact",
     "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_gather_rgb", "pcp_pack_dp3",
     "pcp_voxel_workspace_bytes", "pcp_voxel_downsample", "pcp_sor_workspace_bytes", "pcp_statistical_outlier_removal",
@@ -71,6 +71,7 @@ def load_library():
     L.pcp_backproject_align_crop_multicam.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, pp, vp, vp, vp, vp,
                                                       vp, vp, vp, i64, vp, vp, sz, vp]
     L.pcp_backproject_align_crop_multicam.restype = i32
+    L.pcp_depth_mm_to_m.argtypes = [vp, i64, vp, vp]; L.pcp_depth_mm_to_m.restype = i32
     L.pcp_crop_mask.argtypes = [vp, i64, d3, d3, vp, vp]; L.pcp_crop_mask.restype = i32
     L.pcp_crop_workspace_bytes.argtypes = [i64]; L.pcp_crop_workspace_bytes.restype = sz
     L.pcp_crop_compact.argtypes = [vp, vp, i64, d3, d3, vp, vp, vp, i64, vp, vp, sz, vp]

@@ -12,18 +12,21 @@ from . import _ffi, ops
 
 
 class EpisodeRunner:
-    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=0, Hc=None, Wc=None):
+    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=0, Hc=None, Wc=None, depth_mm=False):
         if not torch.cuda.is_available():
             raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
         self.H, self.W, self.K, self.params, self.chunk = H, W, K, params, int(chunk)
+        self.depth_mm = bool(depth_mm)          # chunks carry raw uint16 millimetres: half the upload, /1000 on the device
         self.Hc, self.Wc = Hc or H, Wc or W
         self.dev = torch.device(device)
         self.pipe = ops.FramePipeline(self.chunk, H, W, K, params, self.dev, dist_mode=dist_mode)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
-        self.h_depth = [mk((self.chunk, H, W), torch.float32) for _ in range(2)]
+        ddt = torch.uint16 if self.depth_mm else torch.float32
+        self.h_depth = [mk((self.chunk, H, W), ddt) for _ in range(2)]
         self.h_rgb = [mk((self.chunk, self.Hc, self.Wc, 3), torch.uint8) for _ in range(2)]
-        self.d_depth = [torch.empty((self.chunk, H, W), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.d_depth = [torch.empty((self.chunk, H, W), dtype=ddt, device=self.dev) for _ in range(2)]
+        self.d_depth_m = torch.empty((self.chunk, H, W), dtype=torch.float32, device=self.dev) if self.depth_mm else None
         self.d_rgb = [torch.empty((self.chunk, self.Hc, self.Wc, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
@@ -60,7 +63,8 @@ class EpisodeRunner:
         while nxt is not None:
             cur_n, cur_slot = nxt[0].shape[0], slot
             main.wait_event(self.uploaded[cur_slot])
-            xyz, col, idx, off = self.pipe.run(self.d_depth[cur_slot], self.d_rgb[cur_slot])
+            dsrc = ops.depth_mm_to_m(self.d_depth[cur_slot], self.d_depth_m) if self.depth_mm else self.d_depth[cur_slot]
+            xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[cur_slot])
             packed = ops.pack_dp3(xyz, col)
             self.consumed[cur_slot].record(main)
             self.h_rows.copy_(packed, non_blocking=True)
@@ -79,7 +83,8 @@ class EpisodeRunner:
 
     def run_arrays(self, depth, rgb):
         T = depth.shape[0]
-        gen = ((np.ascontiguousarray(depth[i:i + self.chunk], dtype=np.float32),
+        ddt = np.uint16 if self.depth_mm else np.float32
+        gen = ((np.ascontiguousarray(depth[i:i + self.chunk], dtype=ddt),
                 np.ascontiguousarray(rgb[i:i + self.chunk], dtype=np.uint8)) for i in range(0, T, self.chunk))
         return self.run_chunks(gen)
 

@@ -70,6 +70,16 @@ def align_colors(pts_cam, rgb, color_intr, T_depth_to_color):
     return colors, mask
 
 
+def depth_mm_to_m(depth_mm, out=None):
+    """uint16 millimetres → float32 metres (XTP:68-72) on the device."""
+    _require_cuda(depth_mm)
+    _chk(depth_mm, torch.uint16, "depth_mm")
+    if out is None:
+        out = torch.empty(depth_mm.shape, dtype=torch.float32, device=depth_mm.device)
+    check(load_library().pcp_depth_mm_to_m(_ptr(depth_mm), depth_mm.numel(), _ptr(out), _stream()))
+    return out
+
+
 class Stage1:
     """Reusable buffers for pcp_backproject_align_crop on (B,H,W) batches."""
 

@@ -73,3 +73,21 @@ def test_direct_zarr_equals_ply_route_rows(tmp_path):
     for t, (d, c) in enumerate(all_frames):
         r = cbind.frame_pipeline(d, c, po, K, 0)
         np.testing.assert_array_equal(got["point_cloud"][t], R.dp3_rows(r["xyz"], r["rgb"]))
+
+
+def test_depth_mm_upload_path_equals_float_path_and_numpy_division():
+    import torch
+    from pcp import _ffi, ops
+    from pcp.episode import EpisodeRunner
+    allv = np.arange(65536, dtype=np.uint16)                           # every representable raw depth
+    got = ops.depth_mm_to_m(torch.from_numpy(allv).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, allv.astype(np.float32) / 1000.0)          # XTP:72
+    H, W, K, T = 60, 80, 64, 11
+    intr = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    rng = np.random.default_rng(8)
+    mm = rng.integers(0, 6000, (T, H, W)).astype(np.uint16)
+    rgb = rng.integers(0, 256, (T, H, W, 3), dtype=np.uint8)
+    p = _ffi.make_params(intr, intr, apply_crop=True)
+    a, ca = EpisodeRunner(H, W, K, p, chunk=4, depth_mm=True).run_arrays(mm, rgb)
+    b, cb = EpisodeRunner(H, W, K, p, chunk=4).run_arrays(mm.astype(np.float32) / 1000.0, rgb)
+    np.testing.assert_array_equal(a, b); np.testing.assert_array_equal(ca, cb)

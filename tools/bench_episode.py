@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the hot path: a 300-frame synthetic episode that starts in HOST memory, streamed
+through pcp.episode.EpisodeRunner (pinned staging, H2D on a copy stream under the previous chunk's kernels,
+(T,K,6) rows back on the host).  Never the headline `value` (bench.py times HBM-resident input)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]
+import numpy as np, torch
+from pcp import _ffi, synth
+from pcp.episode import EpisodeRunner
+
+H, W, K, T = 480, 640, 1024, 300
+intr = synth.intrinsics(H, W)
+p = _ffi.make_params(intr, intr, apply_crop=True)
+depth, rgb = synth.episode(T, seed0=0, H=H, W=W)
+mm = np.rint(depth * 1000).astype(np.uint16)
+out = {}
+for name, kw, d in (("f32_depth", {}, depth), ("u16_depth", {"depth_mm": True}, mm)):
+    for chunk in (100, 150, 300):
+        r = EpisodeRunner(H, W, K, p, chunk=chunk, **kw)
+        r.run_arrays(d, rgb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            rows, _ = r.run_arrays(d, rgb)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        out[f"{name}_chunk{chunk}"] = {"ms_per_episode": round(dt * 1e3, 2), "frames_per_s": round(T / dt, 1)}
+        del r
+print(json.dumps(out), flush=True)

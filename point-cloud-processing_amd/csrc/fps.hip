@@ -675,12 +675,14 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         STAMP(t4);
         {
+            // every low lane fetches its wave's key AND xyz in one LDS round trip; the winner's xyz is then a
+            // readlane away instead of a second, dependent LDS read
             const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
+            const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
             int src;
             const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
-            const float4 cc = pxyz[par * NW + src];
             last = wk ? (int)(~(unsigned)wk) : 0;
-            sx = cc.x; sy = cc.y; sz = cc.z;
+            sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
         }
 #ifdef PCP_FPS_STAMPS
         { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4;

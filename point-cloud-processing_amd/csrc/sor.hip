@@ -42,12 +42,14 @@ __device__ __forceinline__ void sor_insert(double (&best)[KCAP], double d)
     }
 }
 
+// k-th smallest = best[k-1]; written as a running maximum over the first k (ascending) slots so that the
+// compiler keeps the array in registers instead of lowering a dynamic index through scratch memory
 template <int KCAP>
 __device__ __forceinline__ double sor_kth(const double (&best)[KCAP], int k)
 {
     double v = best[0];
 #pragma unroll
-    for (int t = 1; t < KCAP; ++t) v = (t == k - 1) ? best[t] : v;
+    for (int t = 1; t < KCAP; ++t) v = (t < k && best[t] > v) ? best[t] : v;
     return v;
 }
 
@@ -62,12 +64,20 @@ __device__ __forceinline__ long long sor_lower_bound(const unsigned long long* _
     return lo;
 }
 
+// Sorted insertion is ~150 FP64-wide instructions and, written inline, runs for the whole wave whenever ANY of
+// its 64 lanes has a candidate that beats its k-th best — i.e. for almost every candidate (measured: 220
+// VALU instructions per candidate).  So candidates that beat the lane's (slightly stale) bound are only
+// appended to a small per-lane queue in LDS; when some lane's queue is full, all lanes drain theirs in
+// lockstep and the insertion code runs with most lanes doing useful work.
+#define SOR_Q 8
+
 template <int KCAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 1)
 sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
         const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
         int nb, double* __restrict__ avg)
 {
+    __shared__ double queue[SOR_Q * 256];
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= offsets[B]) return;
     const unsigned long long key = keys[j];
@@ -78,37 +88,61 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
     const int k = (long long)nb < M ? nb : (int)M;
     const double px = sxyz[3 * j], py = sxyz[3 * j + 1], pz = sxyz[3 * j + 2];
     const unsigned long long cloud = (unsigned long long)b << 48;
+    double* q = queue + threadIdx.x;        // this lane's queue: q[slot * 256]
     double best[KCAP];
+    double tau = DBL_MAX;                   // candidates >= tau cannot enter the k best (stale between drains: only larger)
+    int qn = 0;
+    auto reset = [&]() {
+#pragma unroll
+        for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+        tau = DBL_MAX;
+        qn = 0;
+    };
+    auto drain = [&]() {
+#pragma unroll
+        for (int sl = 0; sl < SOR_Q; ++sl)
+            if (__any(sl < qn)) sor_insert<KCAP>(best, sl < qn ? q[sl * 256] : DBL_MAX);
+        qn = 0;
+        tau = sor_kth<KCAP>(best, k);
+    };
+    auto push = [&](double d) {
+        if (d < tau) { q[qn * 256] = d; ++qn; }
+        if (__any(qn == SOR_Q)) drain();
+    };
     bool done = false;
     if (M > k) {
         for (int r = 1; r <= SOR_RMAX && !done; ++r) {
-#pragma unroll
-            for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+            reset();
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > 65535 ? 65535 : cz + r;
-            for (int x = cx - r; x <= cx + r; ++x) {
+            // rows nearest the query's own row first (offsets 0,-1,+1,-2,+2,...): the bound tightens early and
+            // fewer candidates of the outer rows have to be queued
+            for (int ix = 0; ix <= 2 * r; ++ix) {
+                const int x = cx + ((ix & 1) ? -((ix + 1) >> 1) : (ix >> 1));
                 if (x < 0 || x > 65535) continue;
-                for (int y = cy - r; y <= cy + r; ++y) {                 // one contiguous key run per (x,y) row
+                for (int iy = 0; iy <= 2 * r; ++iy) {                    // one contiguous key run per (x,y) row
+                    const int y = cy + ((iy & 1) ? -((iy + 1) >> 1) : (iy >> 1));
                     if (y < 0 || y > 65535) continue;
                     const unsigned long long row = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y << 16);
                     const unsigned long long k1 = row | (unsigned long long)z1;
                     for (long long t = sor_lower_bound(keys, lo, hi, row | (unsigned long long)z0); t < hi; ++t) {
                         if (keys[t] > k1) break;
                         const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
-                        sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+                        push(((dx * dx) + (dy * dy)) + (dz * dz));
                     }
                 }
             }
+            drain();
             const double lim = ((double)r * cell) * (1.0 - 1e-9);      // every point closer than this was scanned
-            done = sor_kth<KCAP>(best, k) <= lim * lim;
+            done = tau <= lim * lim;
         }
     }
     if (!done) {                                                     // isolated point or tiny cloud: whole cloud
-#pragma unroll
-        for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+        reset();
         for (long long t = lo; t < hi; ++t) {
             const double dx = px - sxyz[3 * t], dy = py - sxyz[3 * t + 1], dz = pz - sxyz[3 * t + 2];
-            sor_insert<KCAP>(best, ((dx * dx) + (dy * dy)) + (dz * dz));
+            push(((dx * dx) + (dy * dy)) + (dz * dz));
         }
+        drain();
     }
     double s = 0.0;
 #pragma unroll
@@ -119,20 +153,14 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
 
 // One wave per cloud: strictly sequential sums (point order), as std::accumulate does.  The lanes load 64
 // values at a time and turn them into the addends in parallel (0.0 for a skipped value: adding +0.0 to
-// a non-negative running sum is exact), so the serial chain is one v_add_f64 per point with the addend
-// read from a lane into scalar registers.   stats[b] = {mean, std, threshold, 0}
-__device__ __forceinline__ double sor_lane_f64(double v, int t)
-{
-    const long long u = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, t);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)u >> 32), t);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
+// a non-negative running sum is exact); the addends go through LDS so that every lane holds all 64 of them
+// in registers (broadcast reads, issued ahead of the chain) and the serial part is 64 back-to-back
+// v_add_f64.   stats[b] = {mean, std, threshold, 0}
 __global__ void __launch_bounds__(64)
 sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets, double std_ratio,
           double* __restrict__ stats)
 {
+    __shared__ double term_s[64];
     const int b = blockIdx.x, lane = pcp_lane();
     const long long lo = offsets[b], hi = offsets[b + 1];
     const long long M = hi - lo;
@@ -148,8 +176,12 @@ sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets,
             double term;
             if (pass == 0) term = y > 0.0 ? y : 0.0;
             else term = y > 0.0 ? (y - mean) * (y - mean) : 0.0;
+            term_s[lane] = term;                                      // one wave: LDS accesses stay in program order
+            double op[64];
 #pragma unroll
-            for (int t = 0; t < 64; ++t) acc = acc + sor_lane_f64(term, t);
+            for (int t = 0; t < 64; ++t) op[t] = term_s[t];
+#pragma unroll
+            for (int t = 0; t < 64; ++t) acc = acc + op[t];
         }
         res[pass] = acc;
         if (pass == 0) mean = acc / (double)M;
@@ -293,6 +325,8 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
         hipLaunchKernelGGL(sor_knn<8>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
     else if (nb_neighbors <= 16)
         hipLaunchKernelGGL(sor_knn<16>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+    else if (nb_neighbors <= 20)
+        hipLaunchKernelGGL(sor_knn<20>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
     else if (nb_neighbors <= 24)
         hipLaunchKernelGGL(sor_knn<24>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
     else

@@ -759,6 +759,9 @@ static int launch_bucket_as(const float* xyz, const long long* offsets, int B, i
 #define PCP_FPS_SHAPE 0          // 0: wide for small clouds + deep for large; 2: deep only (tuning builds)
 #endif
 #define PCP_FPS_WIDE_MAX (64 * 1024)
+#ifndef PCP_FPS_DEEP_1024_MAX_B
+#define PCP_FPS_DEEP_1024_MAX_B 256
+#endif
 
 template <int MODE>
 static int launch_bucket(const float* xyz, const long long* offsets, int B, int64_t max_pts, int K,
@@ -770,6 +773,11 @@ static int launch_bucket(const float* xyz, const long long* offsets, int B, int6
     int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
                                                           PCP_FPS_WIDE_MAX, st);
     if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
+    // large clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
+    // twice the waves streaming and half the rows per bucket; bigger batches keep two 512-thread workgroups per CU
+    if (B <= PCP_FPS_DEEP_1024_MAX_B)
+        return launch_bucket_as<1024, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
+                                                            PCP_FPS_WIDE_MAX + 1, 0x7fffffff, st);
     return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
                                                        PCP_FPS_WIDE_MAX + 1, 0x7fffffff, st);
 }

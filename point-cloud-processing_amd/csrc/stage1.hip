@@ -131,34 +131,100 @@ k1_dense(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
 // ---- compaction pass 1: predicate ballots + tile counts ------------------------------------
 // grid (tiles, images), image b = b_first + blockIdx.y*b_stride (one camera of every frame when
 // b_stride = cameras); block 256: wave w, round r covers pixels tile*1024 + (w*4+r)*64 + lane.
+//
+// keep = proj_mask && depth range && (crop off || inside the box).  The colour-frame projection that
+// decides proj_mask (a rigid transform, two FP64 divisions, two rints) is more than half of the FP64
+// work, and with the crop on only ~20 % of the pixels still need it after the cheap tests.  So each wave
+// first runs deproject + base transform + box/range tests for its 256 pixels, packs the camera-frame
+// points that passed into LDS, and evaluates the projection for those only — one or two 64-lane batches
+// instead of four.  When more than K1_PACK_MAX pixels pass (crop off, or a frame filled with in-box
+// points) the wave falls back to evaluating every pixel in place.
+#define K1_PACK_MAX 128
+
 __global__ void __launch_bounds__(256)
 k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
          int Wc, DevParams P, unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt,
          int tiles, int b_first, int b_stride)
 {
     __shared__ int wave_cnt[4];
+    __shared__ double pk_cam[4][K1_PACK_MAX][3];
+    __shared__ unsigned char pk_pos[4][K1_PACK_MAX];
+    __shared__ unsigned long long pk_mask[4][4];
     const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
     const int lane = pcp_lane(), wave = threadIdx.x >> 6;
     const float* dframe = depth + (size_t)b * HW;
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
     unsigned long long* mrow = masks + ((size_t)b * tiles + tile) * PCP_TILE_WORDS;
-    int cnt = 0;
     const float invW = 1.0f / (float)W;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    double cam[4][3];
+    unsigned long long pre[4];
+    int npre = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int word = wave * 4 + r;
-        const int i = tile * PCP_TILE + word * 64 + lane;
-        int keep = 0;
+        const int i = tile * PCP_TILE + (wave * 4 + r) * 64 + lane;
+        int ok = 0;
+        cam[r][0] = cam[r][1] = cam[r][2] = 0.0;
         if (i < HW) {
-            PixelOut o;
             int pv, pu;
             pcp_divmod(i, W, invW, &pv, &pu);
-            pixel_math<false>(P, dframe[i], pu, pv, img, Hc, Wc, o);
-            keep = o.keep;
+            const float d = dframe[i];
+            const double z = (double)d;
+            cam[r][0] = (((double)pu - P.dcx) * z) / P.dfx;            // XPC:62
+            cam[r][1] = (((double)pv - P.dcy) * z) / P.dfy;            // XPC:63
+            cam[r][2] = z;
+            ok = (d > P.z_min) && (d < P.z_max);                      // XPC:109 (f32 compares)
+            if (P.apply_crop) {
+                double base[3];
+                rigid3(P.E, P.transform_fma, cam[r][0], cam[r][1], cam[r][2], base);   // XPC:119
+                ok = ok && base[0] > P.lo[0] && base[0] < P.hi[0] && base[1] > P.lo[1] && base[1] < P.hi[1] &&
+                     base[2] > P.lo[2] && base[2] < P.hi[2];          // DP3:35-39
+            }
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) mrow[word] = m;
-        cnt += __popcll(m);
+        pre[r] = __ballot(ok);
+        npre += __popcll(pre[r]);
+    }
+
+    unsigned long long keep[4];
+    if (npre <= K1_PACK_MAX) {                                        // wave-uniform
+        if (lane < 4) pk_mask[wave][lane] = 0ull;
+        int off = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if ((pre[r] >> lane) & 1ull) {
+                const int c = off + __popcll(pre[r] & lt);
+                pk_cam[wave][c][0] = cam[r][0]; pk_cam[wave][c][1] = cam[r][1]; pk_cam[wave][c][2] = cam[r][2];
+                pk_pos[wave][c] = (unsigned char)(r * 64 + lane);
+            }
+            off += __popcll(pre[r]);
+        }
+        for (int c = lane; c < npre; c += 64) {                       // one wave: LDS accesses stay in program order
+            const double cc[3] = {pk_cam[wave][c][0], pk_cam[wave][c][1], pk_cam[wave][c][2]};
+            float col[3];
+            if (align_math<false>(P, cc, img, Hc, Wc, col)) {
+                const int p = pk_pos[wave][c];
+                atomicOr(&pk_mask[wave][p >> 6], 1ull << (p & 63));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) keep[r] = pk_mask[wave][r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int k = 0;
+            if ((pre[r] >> lane) & 1ull) {
+                float col[3];
+                k = align_math<false>(P, cam[r], img, Hc, Wc, col);
+            }
+            keep[r] = __ballot(k);
+        }
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (lane == 0) mrow[wave * 4 + r] = keep[r];
+        cnt += __popcll(keep[r]);
     }
     if (lane == 0) wave_cnt[wave] = cnt;
     __syncthreads();

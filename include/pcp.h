@@ -185,6 +185,19 @@ int pcp_crop_compact(const double* xyz, const double* rgb, int64_t M1,
                      int64_t cap, int64_t* count, void* ws, size_t ws_bytes, void* stream);
 
 /*
+ * The same crop for B clouds at once, rows concatenated CSR style (cloud b owns rows
+ * [offsets[b], offsets[b+1]) of xyz / rgb, total = offsets[B] known to the host): one launch
+ * sequence for a whole directory chunk of the stage-2 loop DP3:68-90.  out_offsets (B+1) i64
+ * receives the CSR offsets of the cropped clouds; row order is preserved inside every cloud.
+ * Workspace: pcp_crop_workspace_bytes(total).
+ */
+int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t* offsets, int B,
+                             int64_t total, const double lo[3], const double hi[3],
+                             double* out_xyz64, float* out_xyz32, double* out_rgb64,
+                             int64_t* out_offsets, int64_t cap,
+                             void* ws, size_t ws_bytes, void* stream);
+
+/*
  * Batched farthest-point sampling — replaces farthest_point_sampling DP3:7-21,
  * i.e. pytorch3d.ops.sample_farthest_points(points=(1,M,3) f32, K=[K]) with
  * random_start_point=False (contract: SURVEY.md §8c).

@@ -129,3 +129,38 @@ extern "C" int pcp_crop_compact(const double* xyz, const double* rgb, int64_t M1
                        out_xyz64, out_xyz32, out_rgb64, (long long)cap);
     return pcp_launch_status();
 }
+
+// B clouds in CSR form at once (the stage-2 script reads many PLYs and crops them in one go): the same
+// flag / scan / scatter passes over the concatenated rows, plus the CSR offsets of the result.
+extern "C" int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t* offsets, int B,
+                                        int64_t total, const double lo[3], const double hi[3],
+                                        double* out_xyz64, float* out_xyz32, double* out_rgb64,
+                                        int64_t* out_offsets, int64_t cap, void* ws, size_t ws_bytes,
+                                        void* stream)
+{
+    if (B < 0 || total < 0 || !lo || !hi || !offsets || !out_offsets || cap < 0 || (total > 0 && !xyz) ||
+        (out_rgb64 && !rgb))
+        return PCP_ERR_INVALID_ARG;
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_crop_workspace_bytes(total)) return PCP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (total == 0 || B == 0) {
+        PCP_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(B + 1), st));
+        return PCP_OK;
+    }
+    const long long tiles = (total + PCP_TILE - 1) / PCP_TILE;
+    if (tiles > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
+    char* w = (char*)ws;
+    unsigned long long* masks = (unsigned long long*)w;
+    w += pcp_align256((size_t)tiles * PCP_TILE_WORDS * 8);
+    int* tile_cnt = (int*)w;
+    w += pcp_align256((size_t)tiles * 4);
+    long long* count = (long long*)w;
+    hipLaunchKernelGGL(crop_flags, dim3((unsigned)tiles), dim3(256), 0, st, xyz, (long long)total,
+                       make_box(lo, hi), (uint8_t*)nullptr, masks, tile_cnt);
+    hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, (int)tiles, count);
+    hipLaunchKernelGGL(crop_scatter, dim3((unsigned)tiles), dim3(256), 0, st, xyz, rgb, masks, tile_cnt,
+                       out_xyz64, out_xyz32, out_rgb64, (long long)cap);
+    hipLaunchKernelGGL(pcp_csr_offsets, dim3((B + 256) / 256), dim3(256), 0, st, (const long long*)offsets, B,
+                       masks, tile_cnt, count, (long long*)out_offsets);
+    return pcp_launch_status();
+}

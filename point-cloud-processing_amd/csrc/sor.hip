@@ -336,7 +336,7 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
     hipLaunchKernelGGL(sor_scatter, dim3(tiles), dim3(256), 0, st, xyz, rgb, off, B, masks, tile_cnt, out_xyz64,
                        out_xyz32, out_rgb32, (long long*)out_index, (long long)cap_out, overflow);
-    hipLaunchKernelGGL(vox_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
+    hipLaunchKernelGGL(pcp_csr_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
                        (long long*)out_offsets);
     return pcp_launch_status();
 }

@@ -282,6 +282,25 @@ pcp_scan_frames(const long long* __restrict__ frame_cnt, int B, long long* __res
     if (threadIdx.x == 0) offsets[B] = carry_s;
 }
 
+// CSR offsets of a compacted batch (shared with crop.hip, voxel.hip, sor.hip): rows [offsets[b], offsets[b+1])
+// of the input belong to cloud b; out_offsets[b] = number of kept rows (set ballot bits) before row offsets[b]
+__global__ void pcp_csr_offsets(const long long* __restrict__ offsets, int B,
+                            const unsigned long long* __restrict__ masks, const int* __restrict__ tile_off,
+                            const long long* __restrict__ total_heads, long long* __restrict__ out_offsets)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > B) return;
+    const long long p = offsets[b], n = offsets[B];
+    if (p >= n) { out_offsets[b] = total_heads[0]; return; }
+    const long long tile = p / PCP_TILE;
+    const int in_tile = (int)(p % PCP_TILE), word = in_tile >> 6, bit = in_tile & 63;
+    long long r = tile_off[tile];
+    for (int w = 0; w < word; ++w) r += __popcll(masks[(size_t)tile * PCP_TILE_WORDS + w]);
+    const unsigned long long low = bit ? (masks[(size_t)tile * PCP_TILE_WORDS + word] & ((1ull << bit) - 1ull)) : 0ull;
+    out_offsets[b] = r + __popcll(low);
+}
+
+
 // ---- compaction pass 2: survivors only -----------------------------------------------------
 __global__ void __launch_bounds__(256)
 k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,

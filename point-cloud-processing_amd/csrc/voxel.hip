@@ -15,7 +15,7 @@
 //   vox_heads    : ballot of "first row of a voxel" per 64 sorted rows + counts per 1024-row tile
 //   pcp_scan_tiles (one sequence)
 //   vox_reduce   : thread t of a tile owns the tile's t-th voxel: walks its run, sums in order, divides
-//   vox_offsets  : CSR offsets of the output clouds from the ballots
+//   pcp_csr_offsets  : CSR offsets of the output clouds from the ballots
 #include "pcp_internal.h"
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -198,23 +198,6 @@ vox_reduce(const unsigned long long* __restrict__ keys, const unsigned int* __re
     }
 }
 
-// out_offsets[b] = number of voxel heads before sorted position offsets[b]
-__global__ void vox_offsets(const long long* __restrict__ offsets, int B,
-                            const unsigned long long* __restrict__ masks, const int* __restrict__ tile_off,
-                            const long long* __restrict__ total_heads, long long* __restrict__ out_offsets)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > B) return;
-    const long long p = offsets[b], n = offsets[B];
-    if (p >= n) { out_offsets[b] = total_heads[0]; return; }
-    const long long tile = p / PCP_TILE;
-    const int in_tile = (int)(p % PCP_TILE), word = in_tile >> 6, bit = in_tile & 63;
-    long long r = tile_off[tile];
-    for (int w = 0; w < word; ++w) r += __popcll(masks[(size_t)tile * PCP_TILE_WORDS + w]);
-    const unsigned long long low = bit ? (masks[(size_t)tile * PCP_TILE_WORDS + word] & ((1ull << bit) - 1ull)) : 0ull;
-    out_offsets[b] = r + __popcll(low);
-}
-
 static size_t vox_sort_temp_bytes(int64_t cap)
 {
     size_t bytes = 0;
@@ -299,7 +282,7 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
     hipLaunchKernelGGL(vox_reduce, dim3(tiles), dim3(256), 0, st, keys_out, vals_out, xyz, rgb, off, B, masks,
                        tile_cnt, out_xyz64, out_xyz32, out_rgb32, out_count, (long long)cap_out, overflow);
-    hipLaunchKernelGGL(vox_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
+    hipLaunchKernelGGL(pcp_csr_offsets, dim3((B + 256) / 256), dim3(256), 0, st, off, B, masks, tile_cnt, total,
                        (long long*)out_offsets);
     return pcp_launch_status();
 }

@@ -10,7 +10,7 @@ EXPORTS = (
     "pcp_default_params", "pcp_strerror", "pcp_version", "pcp_device_count",
     "pcp_backproject_dense", "pcp_align_colors", "pcp_backproject_workspace_bytes", "pcp_backproject_align_crop",
     "pcp_backproject_align_crop_multicam", "pcp_depth_mm_to_m",
-    "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact",
+    "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact", "pcp_crop_compact_batched",
     "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_gather_rgb", "pcp_pack_dp3",
     "pcp_voxel_workspace_bytes", "pcp_voxel_downsample", "pcp_sor_workspace_bytes", "pcp_statistical_outlier_removal",
 )
@@ -76,6 +76,8 @@ def load_library():
     L.pcp_crop_workspace_bytes.argtypes = [i64]; L.pcp_crop_workspace_bytes.restype = sz
     L.pcp_crop_compact.argtypes = [vp, vp, i64, d3, d3, vp, vp, vp, i64, vp, vp, sz, vp]
     L.pcp_crop_compact.restype = i32
+    L.pcp_crop_compact_batched.argtypes = [vp, vp, vp, i32, i64, d3, d3, vp, vp, vp, vp, i64, vp, sz, vp]
+    L.pcp_crop_compact_batched.restype = i32
     L.pcp_fps_workspace_bytes.argtypes = [i32, i64, i64, i32, i32]; L.pcp_fps_workspace_bytes.restype = sz
     L.pcp_fps_batched.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]
     L.pcp_fps_batched.restype = i32

@@ -63,28 +63,77 @@ def save_ply(path, xyz, rgb):
     ply.write_point_cloud(path, xyz, rgb)                                              # DP3:54-58
 
 
+BATCH = int(os.environ.get("PCP_STAGE2_BATCH", "64"))          # clouds per launch sequence in process()
+
+
+def process_point_clouds_batched(clouds, num_points=NUM_POINTS):
+    """process_point_cloud (DP3:23-52) for a list of (pc_xyz, pc_rgb) pairs in ONE launch sequence: batched
+    crop, batched FPS, one colour gather.  Returns [(xyz (K,3) f32, rgb (K,3) f64, cropped_count)]; a cloud
+    with no point inside the workspace yields None (the serial loop raises for it, see process())."""
+    dev = _device()
+    sizes = [int(c[0].shape[0]) for c in clouds]
+    off_h = np.zeros(len(clouds) + 1, np.int64)
+    off_h[1:] = np.cumsum(sizes)
+    xyz = torch.from_numpy(np.ascontiguousarray(np.concatenate([c[0] for c in clouds]), dtype=np.float64)).to(dev)
+    rgb = torch.from_numpy(np.ascontiguousarray(np.concatenate([c[1] for c in clouds]), dtype=np.float64)).to(dev)
+    lo = [w[0] for w in WORK_SPACE]
+    hi = [w[1] for w in WORK_SPACE]
+    _, x32, c64, out_off = ops.crop_compact_batched(xyz, rgb, torch.from_numpy(off_h).to(dev), lo, hi)   # DP3:35-42
+    oo = out_off.cpu().numpy()
+    counts = np.diff(oo)
+    total = int(oo[-1])
+    if total == 0:
+        return [None] * len(clouds)
+    fxyz, idx = ops.fps_batched(x32[:total].contiguous(), out_off, int(num_points), dist_mode=DIST_MODE,
+                                max_pts=int(counts.max()))
+    m = torch.from_numpy(counts).to(dev).unsqueeze(1)
+    sel = torch.where(idx < 0, idx + m, idx).clamp_(min=0) + out_off[:-1].unsqueeze(1)     # DP3:48 numpy negative index
+    col = c64[:max(total, 1)].index_select(0, sel.reshape(-1)).reshape(len(clouds), int(num_points), 3).cpu().numpy()
+    pts = fxyz.cpu().numpy()
+    return [None if counts[b] == 0 else (pts[b], col[b], int(counts[b])) for b in range(len(clouds))]
+
+
 def process(input_root, output_root, verbose=True):
-    """DP3:61-92: every *.ply of input_root → <name>_filtered.ply in output_root."""
+    """DP3:61-92: every *.ply of input_root → <name>_filtered.ply in output_root.  Files are read, processed
+    and written in chunks of BATCH clouds (same outputs, prints and error behaviour as the serial loop)."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(output_root, exist_ok=True)
     names = sorted(f for f in os.listdir(input_root) if f.endswith(".ply"))
     print(f"\n=== Processing folder: {input_root} ({len(names)} clouds) ===")
-    for fn in names:
-        src = os.path.join(input_root, fn)
-        dst = os.path.join(output_root, fn.replace(".ply", "_filtered.ply"))
-        if verbose:
-            print(f"\nProcessing {fn} ...")
-        pc_xyz, pc_rgb = ply.read_point_cloud(src)
-        if pc_xyz.shape[0] == 0:
-            print(f"Warning: Empty point cloud at {src}")                              # DP3:76-78
-            continue
-        if pc_rgb is None:
-            pc_rgb = np.zeros_like(pc_xyz)
-        if verbose:
-            print(f"Loaded XYZ: {pc_xyz.shape} | RGB: {pc_rgb.shape}")
-        xyz_f, rgb_f = process_point_cloud(pc_xyz, pc_rgb, verbose=verbose)
-        save_ply(dst, xyz_f, rgb_f)
-        if verbose:
-            print(f"Saved → {dst}")
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        for c0 in range(0, len(names), BATCH):
+            chunk = names[c0:c0 + BATCH]
+            loaded = list(pool.map(lambda fn: ply.read_point_cloud(os.path.join(input_root, fn)), chunk))
+            keep = [i for i, (xyz, _) in enumerate(loaded) if xyz.shape[0] > 0]
+            clouds = [(loaded[i][0], loaded[i][1] if loaded[i][1] is not None else np.zeros_like(loaded[i][0]))
+                      for i in keep]
+            results = process_point_clouds_batched(clouds) if clouds else []
+            by_file = dict(zip(keep, results))
+            writes = []
+            for i, fn in enumerate(chunk):
+                src = os.path.join(input_root, fn)
+                dst = os.path.join(output_root, fn.replace(".ply", "_filtered.ply"))
+                if verbose:
+                    print(f"\nProcessing {fn} ...")
+                if i not in by_file:
+                    print(f"Warning: Empty point cloud at {src}")                      # DP3:76-78
+                    continue
+                if verbose:
+                    print(f"Loaded XYZ: {clouds[keep.index(i)][0].shape} | RGB: {clouds[keep.index(i)][1].shape}")
+                res = by_file[i]
+                if res is None:
+                    for w in writes:
+                        w.result()
+                    raise ValueError("process_point_cloud: no point inside the workspace")   # reference dies in pytorch3d
+                xyz_f, rgb_f, m = res
+                if verbose:
+                    print(f" → After crop: {m} points")
+                    print(f" → After FPS: {xyz_f.shape[0]} points")
+                writes.append(pool.submit(save_ply, dst, xyz_f, rgb_f))
+                if verbose:
+                    print(f"Saved → {dst}")
+            for w in writes:
+                w.result()
     print(f"\nDone. All filtered clouds saved in {output_root}")
 
 

@@ -169,6 +169,27 @@ def crop_compact(xyz, rgb, lo, hi, want_xyz64=True, want_xyz32=True):
     return cut(o64), cut(o32), cut(orgb), m
 
 
+def crop_compact_batched(xyz, rgb, offsets, lo, hi, want_xyz64=False):
+    """DP3:35-42 on B CSR clouds in one launch sequence → (xyz64 or None, xyz32, rgb64 or None, out_offsets).
+    Outputs keep the input's row capacity; cloud b's rows are [out_offsets[b], out_offsets[b+1])."""
+    _require_cuda(xyz, offsets)
+    _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
+    if rgb is not None:
+        _chk(rgb, torch.float64, "rgb")
+    L = load_library()
+    n, dev, B = xyz.shape[0], xyz.device, offsets.numel() - 1
+    nb = L.pcp_crop_workspace_bytes(n)
+    ws = _workspace(nb, dev)
+    o64 = torch.empty((n, 3), dtype=torch.float64, device=dev) if want_xyz64 else None
+    o32 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    orgb = torch.empty((n, 3), dtype=torch.float64, device=dev) if rgb is not None else None
+    out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
+    check(L.pcp_crop_compact_batched(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, lo3, hi3, _ptr(o64), _ptr(o32),
+                                     _ptr(orgb), _ptr(out_off), n, _ptr(ws), nb, _stream()))
+    return o64, o32, orgb, out_off
+
+
 class Fps:
     """Reusable workspace for pcp_fps_batched."""
 

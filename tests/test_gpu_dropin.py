@@ -116,3 +116,32 @@ def test_stage1_script_then_stage2_cli_end_to_end(tmp_path):
         # the rows chunking_data.py:134-144 would stack for the zarr
         np.testing.assert_array_equal(np.concatenate([xyz, rgb * 255], 1).astype(np.float32),
                                       R.dp3_rows(ref_xyz, ref_rgb))
+
+
+def test_batched_crop_and_batched_stage2_equal_the_per_cloud_path():
+    import torch
+    import pcp.dp3_point_cloud_processing as dp3
+    from pcp import ops
+    rng = np.random.default_rng(44)
+    sizes = [30000, 0, 1, 5000, 2999]
+    clouds = [(rng.uniform(-0.3, 0.8, (n, 3)), rng.integers(0, 256, (n, 3)) / 255.0) for n in sizes]
+    clouds[2] = (np.array([[0.1, 0.1, 0.1]]), np.array([[0.5, 0.25, 1.0]]))             # a single in-box point
+    off = np.zeros(len(sizes) + 1, np.int64); off[1:] = np.cumsum(sizes)
+    xyz = torch.from_numpy(np.concatenate([c[0] for c in clouds])).cuda()
+    rgb = torch.from_numpy(np.concatenate([c[1] for c in clouds])).cuda()
+    lo = [w[0] for w in R.WORK_SPACE]; hi = [w[1] for w in R.WORK_SPACE]
+    o64, o32, orgb, out_off = ops.crop_compact_batched(xyz, rgb, torch.from_numpy(off).cuda(), lo, hi, want_xyz64=True)
+    oo = out_off.cpu().numpy()
+    for b, (p, c) in enumerate(clouds):
+        m = R.crop_mask(p) if len(p) else np.zeros(0, bool)
+        assert oo[b + 1] - oo[b] == m.sum()
+        np.testing.assert_array_equal(o64[oo[b]:oo[b + 1]].cpu().numpy(), p[m])
+        np.testing.assert_array_equal(o32[oo[b]:oo[b + 1]].cpu().numpy(), p[m].astype(np.float32))
+        np.testing.assert_array_equal(orgb[oo[b]:oo[b + 1]].cpu().numpy(), c[m])
+    nonempty = [c for c in clouds if len(c[0])]
+    res = dp3.process_point_clouds_batched(nonempty)
+    for (p, c), r in zip(nonempty, res):
+        ref_xyz, ref_rgb, _ = R.process_point_cloud(p, c)
+        np.testing.assert_array_equal(r[0], ref_xyz)
+        np.testing.assert_array_equal(r[1], ref_rgb)                                       # incl. -1 padding → last colour
+    assert dp3.process_point_clouds_batched([(np.full((4, 3), 9.0), np.zeros((4, 3)))]) == [None]

@@ -238,6 +238,23 @@ def test_fps_ties_on_a_lattice(algo):
     np.testing.assert_array_equal(idx[0], ref_idx)
 
 
+@pytest.mark.parametrize("algo", ALGOS)
+def test_fps_non_finite_points_behave_like_the_oracle(algo):
+    # a NaN distance never lowers min_d (d < min_d is false), so a NaN point keeps the initial maximum and is
+    # picked again and again — degenerate, but brute force, bucket pruning and the oracle must agree on it
+    rng = np.random.default_rng(25)
+    pts = rng.uniform(-0.5, 0.5, (5000, 3)).astype(np.float32)
+    pts[17] = [np.nan, 0.1, 0.2]; pts[400, 2] = np.inf; pts[4000] = [np.nan] * 3; pts[77, 0] = -np.inf
+    ref_xyz, ref_idx = cbind.fps(pts, 64, 0)
+    xyz, idx = run_fps([pts], 64, 0, algo)
+    np.testing.assert_array_equal(idx[0], ref_idx)
+    clean = pts.copy(); clean[400, 2] = np.inf                       # only infinities: distances inf, no NaN
+    clean[17] = [0.0, 0.1, 0.2]; clean[4000] = [0.3, 0.3, 0.3]
+    ref_xyz, ref_idx = cbind.fps(clean, 64, 0)
+    xyz, idx = run_fps([clean], 64, 0, algo)
+    np.testing.assert_array_equal(idx[0], ref_idx)
+
+
 def test_fps_cloud_shapes_cover_every_sort_plan():
     """Cubic clouds sort along the 3-D Hilbert curve, flat ones along the 2-D curve over their two long axes
     (any axis may be the thin one), the rest along the adaptive Morton order: all must give the oracle's picks."""

@@ -633,6 +633,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
 #endif
         };
         bool first = true;
+        __builtin_amdgcn_s_setprio(3);                          // the streaming phase is the round's critical path
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             unsigned long long m = amask[s];
@@ -661,6 +662,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
                 first = false;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (first) idle_argmax();                               // nothing to stream this round
         wmax = cand;                                            // = arg-max over all the wave's buckets again
         wmax_j = cand_j;

@@ -255,6 +255,31 @@ def test_fps_non_finite_points_behave_like_the_oracle(algo):
     np.testing.assert_array_equal(idx[0], ref_idx)
 
 
+@pytest.mark.parametrize("dist_mode", [0, 1])
+def test_fps_batch_of_300_ragged_clouds(dist_mode):
+    """A batch of more clouds than CUs (two workgroups share some CUs) with ragged sizes — empty, single point,
+    fewer points than K, not a multiple of 64, exactly 64 k, one cloud for the deep shape, duplicates and a
+    lattice with ties — must give the oracle's picks for every cloud."""
+    rng = np.random.default_rng(26)
+    K = 96
+    sizes = [0, 1, 2, 63, 64, 65, 95, 96, 97, 1000, 2047, 2048, 4099, 6400]
+    clouds = []
+    for b in range(300):
+        m = sizes[b % len(sizes)] if b < 280 else int(rng.integers(2048, 9000))
+        clouds.append(rng.uniform(-0.5, 0.5, (m, 3)).astype(np.float32))
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(5), indexing="ij"), -1).reshape(-1, 3)
+    clouds[7] = g[rng.permutation(len(g))].astype(np.float32)             # exact ties
+    clouds[263] = np.zeros((3000, 3), np.float32)                          # all duplicates
+    clouds[290] = rng.uniform(-0.5, 0.5, (65536, 3)).astype(np.float32)    # largest size of the wide shape
+    clouds[5] = rng.uniform(-0.5, 0.5, (70000, 3)).astype(np.float32)      # belongs to the deep launch
+    xyz, idx = run_fps(clouds, K, dist_mode, 2)
+    for b, c in enumerate(clouds):
+        if b % 9 == 0 or b in (5, 7, 263, 290) or b >= 256:
+            ref_xyz, ref_idx = cbind.fps(c, K, dist_mode)
+            np.testing.assert_array_equal(idx[b], ref_idx, err_msg=f"cloud {b} M={len(c)}")
+            np.testing.assert_array_equal(xyz[b], ref_xyz, err_msg=f"cloud {b}")
+
+
 def test_fps_cloud_shapes_cover_every_sort_plan():
     """Cubic clouds sort along the 3-D Hilbert curve, flat ones along the 2-D curve over their two long axes
     (any axis may be the thin one), the rest along the adaptive Morton order: all must give the oracle's picks."""

@@ -145,3 +145,18 @@ def test_batched_crop_and_batched_stage2_equal_the_per_cloud_path():
         np.testing.assert_array_equal(r[0], ref_xyz)
         np.testing.assert_array_equal(r[1], ref_rgb)                                       # incl. -1 padding → last colour
     assert dp3.process_point_clouds_batched([(np.full((4, 3), 9.0), np.zeros((4, 3)))]) == [None]
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """examples/fps_from_c (built by __graft_entry__.build() with gcc): the C ABI used without Python or torch."""
+    exe = os.path.join(ROOT, "examples", "fps_from_c")
+    if not os.path.exists(exe):
+        pytest.skip("examples/fps_from_c not built")
+    rng = np.random.default_rng(45)
+    pts = rng.uniform(-0.4, 0.4, (20000, 3)).astype(np.float32)
+    src, dst = str(tmp_path / "cloud.f32"), str(tmp_path / "idx.i64")
+    pts.tofile(src)
+    r = subprocess.run([exe, src, "20000", "300", dst], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gfx950" in r.stdout
+    np.testing.assert_array_equal(np.fromfile(dst, dtype=np.int64), cbind.fps(pts, 300, 0)[1])

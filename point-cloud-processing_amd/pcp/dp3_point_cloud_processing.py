@@ -66,10 +66,12 @@ def save_ply(path, xyz, rgb):
 BATCH = int(os.environ.get("PCP_STAGE2_BATCH", "64"))          # clouds per launch sequence in process()
 
 
-def process_point_clouds_batched(clouds, num_points=NUM_POINTS):
+def process_point_clouds_batched(clouds, num_points=NUM_POINTS, voxel_size=None, sor=None):
     """process_point_cloud (DP3:23-52) for a list of (pc_xyz, pc_rgb) pairs in ONE launch sequence: batched
     crop, batched FPS, one colour gather.  Returns [(xyz (K,3) f32, rgb (K,3) f64, cropped_count)]; a cloud
-    with no point inside the workspace yields None (the serial loop raises for it, see process())."""
+    with no point inside the workspace yields None (the serial loop raises for it, see process()).
+    voxel_size (metres) and sor = (nb_neighbors, std_ratio) insert the BASELINE config-3 filters between crop
+    and FPS (Open3D semantics, no counterpart in the reference; cropped_count is then the filtered count)."""
     dev = _device()
     sizes = [int(c[0].shape[0]) for c in clouds]
     off_h = np.zeros(len(clouds) + 1, np.int64)
@@ -78,12 +80,27 @@ def process_point_clouds_batched(clouds, num_points=NUM_POINTS):
     rgb = torch.from_numpy(np.ascontiguousarray(np.concatenate([c[1] for c in clouds]), dtype=np.float64)).to(dev)
     lo = [w[0] for w in WORK_SPACE]
     hi = [w[1] for w in WORK_SPACE]
-    _, x32, c64, out_off = ops.crop_compact_batched(xyz, rgb, torch.from_numpy(off_h).to(dev), lo, hi)   # DP3:35-42
-    oo = out_off.cpu().numpy()
-    counts = np.diff(oo)
-    total = int(oo[-1])
+    filtered = voxel_size is not None or sor is not None
+    x64, x32, c64, out_off = ops.crop_compact_batched(xyz, rgb, torch.from_numpy(off_h).to(dev), lo, hi,
+                                                      want_xyz64=filtered)                     # DP3:35-42
+    total = int(out_off[-1].item())
     if total == 0:
         return [None] * len(clouds)
+    if filtered:
+        c32 = c64[:total].float().contiguous()
+        x64 = x64[:total].contiguous()
+        if voxel_size is not None:
+            v, out_off = ops.voxel_downsample(x64, c32, out_off, float(voxel_size))
+            total = int(out_off[-1].item())
+            x64, c32 = v["xyz64"][:total].contiguous(), v["rgb32"][:total].contiguous()
+        if sor is not None and total > 0:
+            s, out_off = ops.statistical_outlier_removal(x64, c32, out_off, int(sor[0]), float(sor[1]))
+            total = int(out_off[-1].item())
+            x64, c32 = s["xyz64"][:total].contiguous(), s["rgb32"][:total].contiguous()
+        if total == 0:
+            return [None] * len(clouds)
+        x32, c64 = x64.float().contiguous(), c32.double()
+    counts = np.diff(out_off.cpu().numpy())
     fxyz, idx = ops.fps_batched(x32[:total].contiguous(), out_off, int(num_points), dist_mode=DIST_MODE,
                                 max_pts=int(counts.max()))
     m = torch.from_numpy(counts).to(dev).unsqueeze(1)
@@ -93,9 +110,10 @@ def process_point_clouds_batched(clouds, num_points=NUM_POINTS):
     return [None if counts[b] == 0 else (pts[b], col[b], int(counts[b])) for b in range(len(clouds))]
 
 
-def process(input_root, output_root, verbose=True):
+def process(input_root, output_root, verbose=True, voxel_size=None, sor=None, num_points=NUM_POINTS):
     """DP3:61-92: every *.ply of input_root → <name>_filtered.ply in output_root.  Files are read, processed
-    and written in chunks of BATCH clouds (same outputs, prints and error behaviour as the serial loop)."""
+    and written in chunks of BATCH clouds (same outputs, prints and error behaviour as the serial loop).
+    voxel_size / sor / num_points are the extensions filter_point_clouds.py exposes (defaults = the reference)."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(output_root, exist_ok=True)
     names = sorted(f for f in os.listdir(input_root) if f.endswith(".ply"))
@@ -107,7 +125,7 @@ def process(input_root, output_root, verbose=True):
             keep = [i for i, (xyz, _) in enumerate(loaded) if xyz.shape[0] > 0]
             clouds = [(loaded[i][0], loaded[i][1] if loaded[i][1] is not None else np.zeros_like(loaded[i][0]))
                       for i in keep]
-            results = process_point_clouds_batched(clouds) if clouds else []
+            results = process_point_clouds_batched(clouds, num_points, voxel_size, sor) if clouds else []
             by_file = dict(zip(keep, results))
             writes = []
             for i, fn in enumerate(chunk):

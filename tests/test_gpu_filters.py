@@ -153,3 +153,31 @@ def test_config3_pipeline_720p_voxel_sor_fps4096():
         else:
             idx = fi[0].cpu().numpy()
             assert idx[0] == 0 and len(np.unique(idx)) == K and idx.max() < S
+
+
+def test_filter_point_clouds_cli_runs_config3_filters_on_a_ply_directory(tmp_path):
+    import os, subprocess, sys
+    from pcp import ply
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(9)
+    src, dst = tmp_path / "global_frame", tmp_path / "filtered"
+    src.mkdir()
+    clouds = []
+    for i in range(3):
+        xyz = np.c_[rng.uniform(-0.2, 0.6, (20000, 2)), rng.uniform(-0.1, 0.7, 20000)]
+        rgb = rng.integers(0, 256, (20000, 3)) / 255.0
+        ply.write_point_cloud(str(src / f"pc_{i:05d}.ply"), xyz, rgb)
+        clouds.append((xyz, rgb))
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(root, "point-cloud-processing_amd", "pcp", "filter_point_clouds.py"),
+                        "--input_root", str(src), "--output_root", str(dst), "--num_points", "512", "--voxel_size", "0.01",
+                        "--sor", "20,2.0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for i, (xyz, rgb) in enumerate(clouds):
+        m = R.crop_mask(xyz)
+        v = cbind.voxel_downsample(xyz[m], ply.read_point_cloud(str(src / f"pc_{i:05d}.ply"))[1][m].astype(np.float32), 0.01)
+        s = cbind.statistical_outlier(v["xyz64"], 20, 2.0)
+        pts = v["xyz64"][s["keep"]].astype(np.float32)
+        ref_xyz, ref_idx = cbind.fps(pts, 512, 0)
+        got, _ = ply.read_point_cloud(str(dst / f"pc_{i:05d}_filtered.ply"))
+        np.testing.assert_array_equal(got, ref_xyz.astype(np.float64))

@@ -208,7 +208,10 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *   dist_mode 0: ((dx*dx)+(dy*dy))+(dz*dz), every op rounded to f32 (x86 CPU build of pytorch3d)
  *             1: fmaf(dz,dz,fmaf(dy,dy,dx*dx))   (what nvcc's default contraction emits)
  *   algo      0: auto   1: brute force (every point every round)
- *             2: exact bucket-pruned FPS (same indices, far fewer distance evaluations)
+ *             2: exact bucket-pruned FPS (same indices, far fewer distance evaluations); its first
+ *                rounds defer bucket updates when the batch is large enough for that to pay
+ *             3: as 2 with the deferred rounds always on   4: as 2 with them always off
+ *                (same indices either way; for tests and tuning)
  * `max_pts` is an upper bound on the largest cloud (host-known, e.g. H*W); it
  * sizes the launch, not the result.
  * Ties are broken toward the lowest index; idx[b][0] = 0.  Empty clouds give

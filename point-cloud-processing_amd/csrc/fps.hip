@@ -451,6 +451,191 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
 #endif
 }
 
+// ---- deferred bucket updates for the early, bandwidth-bound rounds ---------------------------------
+// Same picks as the eager round loop of fps_bucket_body, about half the bucket loads.  A bucket the new
+// sample could change (lb < bucket_max) is not streamed at once: the sample's round number joins the
+// bucket's PENDING list (up to three 10-bit round numbers + a 2-bit count in one register of the owning
+// lane) and the bucket's key stays what it was — now an UPPER BOUND of its arg-max key, because min_d
+// only ever decreases.  A bucket is streamed ("flushed": every pending sample applied in one pass over
+// its rows, the samples read back from an LDS table of the picks so far) when its list is full or when
+// its upper bound reaches tau = ALPHA x (the previous round's winning distance), i.e. when it could win
+// this round.  After the barrier the winner among the CLEAN buckets (no pending sample: key exact) is
+// certain if its distance is >= tau, since every bucket still pending has an upper bound < tau.
+// Otherwise (a few % of the rounds) tau drops to that distance, the pending buckets at or above it are
+// flushed, and the second pick is certain for the same reason.  The winning distances never increase
+// from round to round, so ALPHA only trades early flushes against second iterations; it cannot change a
+// pick.  Fewer loads, but a longer instruction chain per flush: it pays while the rounds are bound by
+// fabric bandwidth (many clouds resident, the first few hundred rounds) and not after, so the host
+// passes the number of rounds to run this way and the eager loop takes over from there.
+#ifndef PCP_FPS_LAZY_ALPHA
+#define PCP_FPS_LAZY_ALPHA 0.95f
+#endif
+#ifndef PCP_FPS_LAZY_ROUNDS
+#define PCP_FPS_LAZY_ROUNDS 256          // rounds run with deferred updates ...
+#endif
+#ifndef PCP_FPS_LAZY_MIN_B
+#define PCP_FPS_LAZY_MIN_B 192           // ... for batches of at least this many clouds
+#endif
+#define PCP_FPS_LAZY_MAX_ROUNDS 1024     // 10-bit round numbers; the sample table reuses the 16 KB cell histogram
+
+// Runs rounds 0..ks-1 (ks <= kn-1, ks <= MAX_ROUNDS) for a single-chunk, one-bucket-per-lane workgroup and
+// leaves every bucket clean.  On return (sx,sy,sz,last) is pick ks, not yet written to the outputs.
+template <int T, int MODE>
+__device__ __forceinline__ void
+fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
+                float4* samp, unsigned long long* pkey, float4* pxyz, float4* bxyz, long long* __restrict__ irow,
+                float* __restrict__ orow, const int tid, const int lane, const int wave, unsigned long long& key,
+                const float (&blo)[3], const float (&bhi)[3], float& sx, float& sy, float& sz, int& last,
+                unsigned long long& wmax, int& wmax_j)
+{
+    constexpr int NW = T / 64, PEND = 3;
+    unsigned pend = 0u;                                         // [count:2][round:10][round:10][round:10]
+    float tau = 0.f;                                            // round 0 flushes every bucket
+    bool fresh = true;                                          // a new sample was picked: test + append
+    bool draining = false;                                      // last trip: flush whatever is still pending
+    for (int k = 0, it = 0;; ++it) {
+        const int par = it & 1;
+        bool need_idle = false;
+        if (fresh) {
+            if (k >= ks) { draining = true; tau = 0.f; }
+            else {
+                if (tid == 0) {
+                    irow[k] = last;
+                    if (orow) { orow[3 * k] = sx; orow[3 * k + 1] = sy; orow[3 * k + 2] = sz; }
+                }
+                // every wave writes the (same) table entry itself: a wave's LDS accesses stay in program
+                // order, so its own flushes read it back without a barrier
+                if (lane == 0) samp[k] = make_float4(sx, sy, sz, 0.f);
+                const float cmax = __uint_as_float((unsigned)(key >> 32));
+                const float qx = __builtin_amdgcn_fmed3f(sx, blo[0], bhi[0]);
+                const float qy = __builtin_amdgcn_fmed3f(sy, blo[1], bhi[1]);
+                const float qz = __builtin_amdgcn_fmed3f(sz, blo[2], bhi[2]);
+                const bool aff = dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax;
+                if (aff) {
+                    const unsigned np = pend >> 30;             // < PEND: a full list was flushed in its round
+                    pend = (pend & 0x3fffffffu) | ((unsigned)k << (10u * np)) | ((np + 1u) << 30);
+                }
+                need_idle = (__ballot(aff) >> ((wmax_j / NW) & 63)) & 1ull;  // the wave's clean top is no longer clean
+            }
+        }
+        const unsigned long long amask =
+            __ballot((pend >> 30) != 0u && (__uint_as_float((unsigned)(key >> 32)) >= tau || (pend >> 30) == (unsigned)PEND));
+        unsigned long long cand = wmax;
+        int cand_j = wmax_j;
+        auto idle_argmax = [&]() {
+            if (!need_idle) return;                             // wave-uniform
+            int src;
+            cand = wave_argmax_key(pend == 0u ? key : 0ull, &src);           // flushing lanes still hold pend != 0
+            cand_j = src * NW + wave;
+        };
+        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], bool first) {
+            constexpr int G = decltype(GC)::value;
+            constexpr bool FULL = decltype(FC)::value;
+            int r0[G];
+            unsigned pw[G];
+            float4 pt[G];
+            float mm[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                r0[u] = (ol[u] * NW + wave) * 64;
+                if (FULL) {
+                    pt[u] = (S + r0[u])[lane];
+                    mm[u] = (D + r0[u])[lane];
+                } else {
+                    const int r = min(r0[u] + lane, M - 1);
+                    pt[u] = S[r];
+                    mm[u] = D[r];
+                }
+                pw[u] = (unsigned)__builtin_amdgcn_readlane((int)pend, ol[u]);
+            }
+            // lane 4u+i fetches pending sample i of bucket u (slots past the count read some valid entry, unused)
+            unsigned w = pw[0];
+#pragma unroll
+            for (int u = 1; u < G; ++u) w = (lane >> 2) == u ? pw[u] : w;
+            const float4 sm = samp[(w >> (10u * (unsigned)(lane & 3))) & 1023u];
+            if (first) idle_argmax();                           // VALU work under the memory latency
+            unsigned long long bk[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int r = r0[u] + lane;
+                const bool live = FULL || r < M;
+                const unsigned np = pw[u] >> 30;                // wave-uniform, 1..PEND
+                float m = mm[u];
+#pragma unroll
+                for (int i = 0; i < PEND; ++i) {
+                    if (i < (int)np)                            // fminf keeps m when d is NaN, like the `d < m` update
+                        m = fminf(m, dist2<MODE>(rl(sm.x, 4 * u + i), rl(sm.y, 4 * u + i), rl(sm.z, 4 * u + i),
+                                                 pt[u].x, pt[u].y, pt[u].z));
+                }
+                if (live && m < mm[u]) D[r] = m;
+                bk[u] = live ? make_key(m, (unsigned)__float_as_int(pt[u].w)) : 0ull;
+            }
+            unsigned long long wk[G];
+            int src[G];
+            wave_argmax_key_x<G>(bk, wk, src);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int j = ol[u] * NW + wave;
+                if (lane == src[u]) bxyz[j] = pt[u];
+                if (lane == ol[u]) { key = wk[u]; pend = 0u; }
+                if (wk[u] > cand) { cand = wk[u]; cand_j = j; }          // scalar
+            }
+        };
+        bool first = true;
+        __builtin_amdgcn_s_setprio(3);
+        {
+            unsigned long long m = amask;
+            while (m) {                                         // wave-uniform
+                int ol[4], n = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                    else ol[u] = ol[0];
+                }
+                using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                using I4 = std::integral_constant<int, 4>;
+                const bool full = (M % 64 == 0) || (((NB - 1) % NW) != wave) || !((amask >> (((NB - 1) / NW) & 63)) & 1ull);
+                if (full) {
+                    if (n == 1) run_pass(I1{}, std::true_type{}, ol, first);
+                    else if (n == 2) run_pass(I2{}, std::true_type{}, ol, first);
+                    else run_pass(I4{}, std::true_type{}, ol, first);
+                } else {
+                    run_pass(I4{}, std::false_type{}, ol, first);
+                }
+                first = false;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (first) idle_argmax();
+        wmax = cand;
+        wmax_j = cand_j;
+        if (draining) break;                                    // every bucket clean, each wave's top exact: no pick needed
+        if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // see the eager loop
+        {
+            const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
+            const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
+            int src;
+            const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
+            const float v = __uint_as_float((unsigned)(wk >> 32));
+            if (!fresh || v >= tau) {                           // certain: every pending bucket is bounded below tau <= v
+                last = wk ? (int)(~(unsigned)wk) : 0;
+                sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
+                tau = PCP_FPS_LAZY_ALPHA * v;
+                fresh = true;
+                ++k;
+            } else {                                            // flush the pending buckets that could still beat v
+                tau = v;
+                fresh = false;
+            }
+        }
+    }
+    __syncthreads();                                            // the eager loop restarts the partials' parity
+}
+
 template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
@@ -461,7 +646,7 @@ template <int T, int CPL, bool MULTI, int MODE>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
 {
     // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
     constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
@@ -532,7 +717,15 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     STAMP(tp1);
 
     // ---- rounds -------------------------------------------------------------------------------------
-    for (int k = 0;; ++k) {
+    int k0 = 0;
+    if constexpr (!MULTI && CPL == 1) {
+        static_assert(PCP_FPS_NCELL * 4 >= PCP_FPS_LAZY_MAX_ROUNDS * 16, "the sample table reuses the cell histogram");
+        k0 = min(min(lazy_k, PCP_FPS_LAZY_MAX_ROUNDS), kn - 1);
+        if (k0 > 0)                                             // workgroup-uniform
+            fps_lazy_rounds<T, MODE>(k0, M, NB, S, D, (float4*)cellcnt, pkey, pxyz, bxyz, irow, orow, tid, lane, wave,
+                                     key[0], blo[0], bhi[0], sx, sy, sz, last, wmax, wmax_j);
+    }
+    for (int k = k0;; ++k) {
         if (tid == 0) {
             irow[k] = last;
             if (orow) { orow[3 * k] = sx; orow[3 * k + 1] = sy; orow[3 * k + 2] = sz; }
@@ -708,9 +901,9 @@ template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T, 2048 / T) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
 fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
 {
-    fps_bucket_body<T, CPL, false, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
+    fps_bucket_body<T, CPL, false, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
 }
 
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
@@ -718,15 +911,16 @@ template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
 fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
 {
-    fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
+    fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
 }
 
 // ---- host entry points -------------------------------------------------------------------------
 static int fps_pick_algo(int algo, int64_t max_pts)
 {
-    if (algo != 0) return algo;
+    if (algo >= 2) return 2;                 // 3 / 4: bucket kernels with the deferred rounds forced on / off
+    if (algo == 1) return 1;
     return max_pts >= 2048 ? 2 : 1;
 }
 
@@ -745,15 +939,18 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
 // its cloud by its actual size (a dropped workgroup exits at once).
 template <int T, int CPL, bool MULTI, int MODE>
 static int launch_bucket_as(const float* xyz, const long long* offsets, int B, int K, long long* idx,
-                            float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, hipStream_t st)
+                            float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, int lazy, hipStream_t st)
 {
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
-    void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int);
+    void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
     else kern = fps_bucket_wide<T, CPL, MODE>;
+    // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
+    // (lazy: 0 = by batch size, 1 = always, -1 = never)
+    const int lazy_k = (!MULTI && CPL == 1 && lazy >= 0 && (lazy > 0 || B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;
     if (lds > 48 * 1024)
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
     return pcp_launch_status();
 }
 
@@ -767,21 +964,21 @@ static int launch_bucket_as(const float* xyz, const long long* offsets, int B, i
 
 template <int MODE>
 static int launch_bucket(const float* xyz, const long long* offsets, int B, int64_t max_pts, int K,
-                         long long* idx, float* out_xyz, float4* pts4, float* md, hipStream_t st)
+                         long long* idx, float* out_xyz, float4* pts4, float* md, int lazy, hipStream_t st)
 {
     if (PCP_FPS_SHAPE == 2)
         return launch_bucket_as<512, 2, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
-                                                           PCP_FPS_WIDE_MAX, st);
+                                                           PCP_FPS_WIDE_MAX, lazy, st);
     int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
-                                                          PCP_FPS_WIDE_MAX, st);
+                                                          PCP_FPS_WIDE_MAX, lazy, st);
     if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
     // large clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
     // twice the waves streaming and half the rows per bucket; bigger batches keep two 512-thread workgroups per CU
     if (B <= PCP_FPS_DEEP_1024_MAX_B)
         return launch_bucket_as<1024, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                            PCP_FPS_WIDE_MAX + 1, 0x7fffffff, st);
+                                                            PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
     return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                       PCP_FPS_WIDE_MAX + 1, 0x7fffffff, st);
+                                                       PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
 }
 
 extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
@@ -789,7 +986,7 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
                                float* out_xyz, void* ws, size_t ws_bytes, void* stream)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
-        algo < 0 || algo > 2)
+        algo < 0 || algo > 4)
         return PCP_ERR_INVALID_ARG;
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
@@ -800,9 +997,11 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
     float4* pts4 = (float4*)ws;
     float* md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
     const long long* off = (const long long*)offsets;
-    if (fps_pick_algo(algo, max_pts) == 2)
-        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, st)
-                              : launch_bucket<1>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, st);
+    if (fps_pick_algo(algo, max_pts) == 2) {
+        const int lazy = algo == 3 ? 1 : (algo == 4 ? -1 : 0);
+        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, lazy, st)
+                              : launch_bucket<1>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, lazy, st);
+    }
     if (dist_mode == 0)
         hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
     else

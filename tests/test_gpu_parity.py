@@ -179,7 +179,7 @@ def run_fps(clouds, K, dist_mode=0, algo=0):
     return xyz.cpu().numpy(), idx.cpu().numpy()
 
 
-ALGOS = [1, 2]
+ALGOS = [1, 2, 3, 4]      # brute force, bucket (auto), bucket with deferred rounds forced on / off
 
 
 @pytest.mark.parametrize("algo", ALGOS)

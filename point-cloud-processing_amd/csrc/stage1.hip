@@ -28,6 +28,14 @@ struct PixelOut {
     int proj, valid, inbox, keep;
 };
 
+// (float)((double)i / 255.0) for i = 0..255 (XPC:77), folded at compile time with IEEE rounding: the 256 possible
+// colour values instead of three FP64 divisions per survivor
+struct K1UnitLut {
+    float v[256];
+    constexpr K1UnitLut() : v() { for (int i = 0; i < 256; ++i) v[i] = (float)((double)i / 255.0); }
+};
+__constant__ const K1UnitLut k1_unit_lut = K1UnitLut();
+
 // rows 0..2 of a 4x4 applied to (x,y,z,1)
 __device__ __forceinline__ void rigid3(const double* r, int use_fma, double x, double y, double z,
                                        double* o)
@@ -67,7 +75,7 @@ __device__ __forceinline__ int align_math(const DevParams& P, const double* cam,
     if (NEED_COLOR && proj && rgb) {
         const uint8_t* px = rgb + ((size_t)(long long)vr * Wc + (size_t)(long long)ur) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) col[c] = (float)((double)px[c] / 255.0);   // XPC:77
+        for (int c = 0; c < 3; ++c) col[c] = k1_unit_lut.v[px[c]];             // XPC:77
     }
     return proj;
 }

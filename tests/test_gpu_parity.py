@@ -280,7 +280,8 @@ def test_fps_batch_of_300_ragged_clouds(dist_mode):
             np.testing.assert_array_equal(xyz[b], ref_xyz, err_msg=f"cloud {b}")
 
 
-def test_fps_cloud_shapes_cover_every_sort_plan():
+@pytest.mark.parametrize("algo", [2, 3])
+def test_fps_cloud_shapes_cover_every_sort_plan(algo):
     """Cubic clouds sort along the 3-D Hilbert curve, flat ones along the 2-D curve over their two long axes
     (any axis may be the thin one), the rest along the adaptive Morton order: all must give the oracle's picks."""
     rng = np.random.default_rng(24)
@@ -297,7 +298,7 @@ def test_fps_cloud_shapes_cover_every_sort_plan():
         "tabletop": np.c_[u(-0.05, 0.4), u(-0.12, 0.35), 0.02 + 0.002 * rng.standard_normal(n) + (rng.random(n) < 0.15) * u(0, 0.12)],
     }
     clouds = [v.astype(np.float32) for v in shapes.values()]
-    xyz, idx = run_fps(clouds, 512, 0, 2)
+    xyz, idx = run_fps(clouds, 512, 0, algo)
     for b, (name, c) in enumerate(zip(shapes, clouds)):
         ref_xyz, ref_idx = cbind.fps(c, 512, 0)
         np.testing.assert_array_equal(idx[b], ref_idx, err_msg=name)
@@ -316,6 +317,21 @@ def test_fps_bench_frame_60k_points(algo):
         xyz, idx = run_fps([pts], K, 0, algo)
         np.testing.assert_array_equal(idx[0], ref_idx)
         np.testing.assert_array_equal(xyz[0], ref_xyz)
+
+
+@pytest.mark.parametrize("dist_mode", [0, 1])
+def test_fps_deferred_rounds_hand_over_to_the_eager_loop(dist_mode):
+    """algo 3 runs the first 256 rounds with deferred bucket updates, drains the pending lists and continues with
+    the eager loop: K just below, at and above the hand-over, and clouds whose size ends the rounds before it."""
+    rng = np.random.default_rng(27)
+    sizes = [60000, 255, 256, 257, 258, 300, 5000, 64, 4096]
+    clouds = [(rng.normal(0, 0.3, (m, 3)) * np.array([1.0, 0.7, 0.1])).astype(np.float32) for m in sizes]
+    for K in (255, 256, 257, 258, 700):
+        xyz, idx = run_fps(clouds, K, dist_mode, 3)
+        for b, c in enumerate(clouds):
+            ref_xyz, ref_idx = cbind.fps(c, K, dist_mode)
+            np.testing.assert_array_equal(idx[b], ref_idx, err_msg=f"K={K} M={len(c)}")
+            np.testing.assert_array_equal(xyz[b], ref_xyz, err_msg=f"K={K} M={len(c)}")
 
 
 # ---------------------------------------------------------------- gather / pack / whole pipeline

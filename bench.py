@@ -42,17 +42,18 @@ def measured_traffic():
     return t.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
 
 
-def cpu_baseline(budget_s=12.0, max_frames=600):
+def cpu_baseline(budget_s=12.0, max_frames=600, scene="random"):
     """The C oracle ("port" of the reference's per-frame path) on this box's host cores,
     single thread like the reference's serial loops, on a bounded sample of the same episode."""
     from oracle import cbind
     from pcp import synth
     intr = synth.intrinsics(H, W)
     po = cbind.make_params(intr, intr, apply_crop=1)
-    cbind.frame_pipeline(*synth.frame(10_000, H, W), po, K_FPS, 0)       # warm (page in, build)
+    make = synth.frame if scene == "random" else synth.scene_frame
+    cbind.frame_pipeline(*make(10_000, H, W), po, K_FPS, 0)              # warm (page in, build)
     n, t_total = 0, 0.0
     while n < max_frames and t_total < budget_s:
-        d, c = synth.frame(n, H, W)
+        d, c = make(n, H, W)
         t0 = time.perf_counter()
         cbind.frame_pipeline(d, c, po, K_FPS, 0)
         t_total += time.perf_counter() - t0
@@ -71,6 +72,8 @@ def main():
     ap.add_argument("--algo", type=int, default=0, help="FPS algorithm (0 auto, 1 brute, 2 bucket)")
     ap.add_argument("--dist-mode", type=int, default=0, help="0: un-fused f32 distance (pytorch3d CPU build), 1: fused (CUDA build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene", choices=["random", "tabletop"], default="random",
+                    help="random: BASELINE's uniform-depth frames (default); tabletop: ray-cast table + boxes (SURVEY 8d)")
     ap.add_argument("--streams", type=int, default=1,
                     help="opt-in: N buffer sets + HIP streams, step i on stream i %% N (consecutive episodes overlap)")
     args = ap.parse_args()
@@ -81,7 +84,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    ndev = torch.cuda.device_count()
+    from pcp import synth
+    make_episode = synth.episode if args.scene == "random" else synth.scene_episode
+    depth_h, rgb_h = make_episode(args.frames, seed0=rank * 1000, H=H, W=W)    # rank r = episode r; made before the
+    ndev = torch.cuda.device_count()                                            # GPU is touched (scene_episode forks)
     local_dev = local % max(ndev, 1)                 # rehearsals with more ranks than GPUs share devices
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -97,7 +103,6 @@ def main():
     intr = synth.intrinsics(H, W)
     params = _ffi.make_params(intr, intr, apply_crop=True)
     B = args.frames
-    depth_h, rgb_h = synth.episode(B, seed0=rank * 1000, H=H, W=W)   # rank r = episode r
     depth = torch.from_numpy(depth_h).to(dev)
     rgb = torch.from_numpy(rgb_h).to(dev)
     del depth_h, rgb_h
@@ -176,7 +181,7 @@ def main():
                                    f"640x480 depth+RGB -> crop -> {K_FPS}-pt FPS, resident in HBM",
                        "frames_per_step_per_gpu": B, "K": K_FPS, "mean_points_after_crop": m_mean,
                        "fps_algo": args.algo, "dist_mode": "nofma" if args.dist_mode == 0 else "fma",
-                       "streams": nbuf},
+                       "streams": nbuf, "scene": args.scene},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
                          "traffic_source": measured_traffic()[1],
@@ -184,7 +189,7 @@ def main():
                          "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(scene=args.scene)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

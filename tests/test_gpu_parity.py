@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import cbind, numpy_ref as R
-from pcp import _ffi, ops
+from pcp import _ffi, ops, synth
 from helpers import load_npz, load_digests, intr_dict, synth_frame, bench_intr
 
 pytestmark = pytest.mark.gpu
@@ -369,6 +369,24 @@ def test_frame_pipeline_vs_oracle_config1():
             np.testing.assert_array_equal(idx[b].cpu().numpy(), ref["idx"])
             np.testing.assert_array_equal(xyz[b].cpu().numpy(), ref["xyz"])
             np.testing.assert_array_equal(col[b].cpu().numpy(), ref["rgb"])
+
+
+def test_frame_pipeline_vs_oracle_on_tabletop_scenes():
+    """SURVEY.md 8d's second input distribution: a ray-cast table with boxes.  The cropped cloud is a smooth sheet
+    of ~72 k points (more than the wide FPS shape takes, so these frames run the deep shape), with dropped pixels."""
+    intr = bench_intr()
+    frames = [synth.scene_frame(s) for s in (0, 5)]
+    p = _ffi.make_params(intr, intr, apply_crop=True)
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    pipe = ops.FramePipeline(len(frames), 480, 640, 1024, p, DEV)
+    xyz, col, idx, off = pipe.run(dev(np.stack([f[0] for f in frames])), dev(np.stack([f[1] for f in frames])))
+    torch.cuda.synchronize()
+    for b, (d, c) in enumerate(frames):
+        ref = cbind.frame_pipeline(d, c, po, 1024, 0)
+        assert 60000 < ref["M"] < 110000 and int(off[b + 1] - off[b]) == ref["M"]
+        np.testing.assert_array_equal(idx[b].cpu().numpy(), ref["idx"])
+        np.testing.assert_array_equal(xyz[b].cpu().numpy(), ref["xyz"])
+        np.testing.assert_array_equal(col[b].cpu().numpy(), ref["rgb"])
 
 
 def test_fps_properties_at_full_size():

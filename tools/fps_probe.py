@@ -14,11 +14,12 @@ ap.add_argument("--algo", type=int, default=2)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--H", type=int, default=480); ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--f", type=float, default=605.0)
+ap.add_argument("--scene", choices=["random", "tabletop"], default="random")
 a = ap.parse_args()
 dev = "cuda"
 intr = synth.intrinsics(a.H, a.W, a.f)
 p = _ffi.make_params(intr, intr, apply_crop=True)
-d, c = synth.episode(a.frames, 0, a.H, a.W)
+d, c = (synth.episode if a.scene == "random" else synth.scene_episode)(a.frames, 0, a.H, a.W)
 s1 = ops.Stage1(a.frames, a.H, a.W, dev, want=("xyz32",))
 out, off = s1.run(torch.from_numpy(d).to(dev), torch.from_numpy(c).to(dev), p)
 torch.cuda.synchronize()

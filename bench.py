@@ -183,8 +183,10 @@ def main():
                        "fps_algo": args.algo, "dist_mode": "nofma" if args.dist_mode == 0 else "fma",
                        "streams": nbuf, "scene": args.scene},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic()[0],
-                         "traffic_source": measured_traffic()[1],
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # the committed PMC passes were taken on the default (random-depth) workload
+                         "traffic": measured_traffic()[0] if args.scene == "random" else None,
+                         "traffic_source": measured_traffic()[1] if args.scene == "random" else None,
                          "kernel": "fps (pcp_fps_batched launches)", "kernel_ms_per_launch": fps_ms,
                          "algorithmic_bytes_per_launch": B * BYTES_PER_FRAME},
         }

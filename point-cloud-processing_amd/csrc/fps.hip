@@ -480,7 +480,7 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
 
 // Runs rounds 0..ks-1 (ks <= kn-1, ks <= MAX_ROUNDS) for a single-chunk, one-bucket-per-lane workgroup and
 // leaves every bucket clean.  On return (sx,sy,sz,last) is pick ks, not yet written to the outputs.
-template <int T, int MODE>
+template <int T, int MODE, int BH>
 __device__ __forceinline__ void
 fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
                 float4* samp, unsigned long long* pkey, float4* pxyz, float4* bxyz, long long* __restrict__ irow,
@@ -488,7 +488,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
                 const float (&blo)[3], const float (&bhi)[3], float& sx, float& sy, float& sz, int& last,
                 unsigned long long& wmax, int& wmax_j)
 {
-    constexpr int NW = T / 64, PEND = 3;
+    constexpr int NW = T / 64, PEND = 3, BS = 64 * BH;
     unsigned pend = 0u;                                         // [count:2][round:10][round:10][round:10]
     float tau = 0.f;                                            // round 0 flushes every bucket
     bool fresh = true;                                          // a new sample was picked: test + append
@@ -537,7 +537,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             float mm[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                r0[u] = (ol[u] * NW + wave) * 64;
+                r0[u] = (ol[u] * NW + wave) * BS + (BH == 2 ? (u & 1) * 64 : 0);     // BH = 2: slots 2p, 2p+1 = one bucket's halves
                 if (FULL) {
                     pt[u] = (S + r0[u])[lane];
                     mm[u] = (D + r0[u])[lane];
@@ -576,12 +576,27 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             unsigned long long wk[G];
             int src[G];
             wave_argmax_key_x<G>(bk, wk, src);
+            if constexpr (BH == 2 && G < 2) {
+                // never called: halved buckets occupy slot pairs
+            } else if constexpr (BH == 2) {
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int j = ol[u] * NW + wave;
-                if (lane == src[u]) bxyz[j] = pt[u];
-                if (lane == ol[u]) { key = wk[u]; pend = 0u; }
-                if (wk[u] > cand) { cand = wk[u]; cand_j = j; }          // scalar
+                for (int q = 0; q < G; q += 2) {
+                    const int j = ol[q] * NW + wave;
+                    const bool hi = wk[q + 1] > wk[q];          // scalar
+                    const unsigned long long wb = hi ? wk[q + 1] : wk[q];
+                    if (hi) { if (lane == src[q + 1]) bxyz[j] = pt[q + 1]; }
+                    else { if (lane == src[q]) bxyz[j] = pt[q]; }
+                    if (lane == ol[q]) { key = wb; pend = 0u; }
+                    if (wb > cand) { cand = wb; cand_j = j; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int j = ol[u] * NW + wave;
+                    if (lane == src[u]) bxyz[j] = pt[u];
+                    if (lane == ol[u]) { key = wk[u]; pend = 0u; }
+                    if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
+                }
             }
         };
         bool first = true;
@@ -590,14 +605,23 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             unsigned long long m = amask;
             while (m) {                                         // wave-uniform
                 int ol[4], n = 0;
+                if constexpr (BH == 2) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
-                    else ol[u] = ol[0];
+                    for (int u = 0; u < 4; u += 2) {
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 2; }
+                        else ol[u] = ol[0];
+                        ol[u + 1] = ol[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                        else ol[u] = ol[0];
+                    }
                 }
                 using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
                 using I4 = std::integral_constant<int, 4>;
-                const bool full = (M % 64 == 0) || (((NB - 1) % NW) != wave) || !((amask >> (((NB - 1) / NW) & 63)) & 1ull);
+                const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || !((amask >> (((NB - 1) / NW) & 63)) & 1ull);
                 if (full) {
                     if (n == 1) run_pass(I1{}, std::true_type{}, ol, first);
                     else if (n == 2) run_pass(I2{}, std::true_type{}, ol, first);
@@ -642,7 +666,7 @@ constexpr size_t fps_bucket_lds_bytes()
     return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
 }
 
-template <int T, int CPL, bool MULTI, int MODE>
+template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
@@ -683,8 +707,11 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
 
     // ---- prologue 3: buckets and their owners ---------------------------------------------------------
     // 64-row chunks per bucket; the single-chunk shape is only launched for clouds of <= 64·NBMAX points
+    // (BH = 2, single-chunk shape only: buckets of two 64-row halves that are streamed side by side, for clouds of
+    //  up to 128·NBMAX points)
+    static_assert(BH == 1 || (BH == 2 && !MULTI && CPL == 1), "halved buckets are a variant of the wide shape");
     const int chunks = MULTI ? (M + 64 * NBMAX - 1) / (64 * NBMAX) : 1;
-    const int BS = 64 * chunks;
+    const int BS = 64 * chunks * BH;
     const int NB = (M + BS - 1) / BS;
     unsigned long long key[CPL];
     float blo[CPL][3], bhi[CPL][3];
@@ -722,7 +749,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         static_assert(PCP_FPS_NCELL * 4 >= PCP_FPS_LAZY_MAX_ROUNDS * 16, "the sample table reuses the cell histogram");
         k0 = min(min(lazy_k, PCP_FPS_LAZY_MAX_ROUNDS), kn - 1);
         if (k0 > 0)                                             // workgroup-uniform
-            fps_lazy_rounds<T, MODE>(k0, M, NB, S, D, (float4*)cellcnt, pkey, pxyz, bxyz, irow, orow, tid, lane, wave,
+            fps_lazy_rounds<T, MODE, BH>(k0, M, NB, S, D, (float4*)cellcnt, pkey, pxyz, bxyz, irow, orow, tid, lane, wave,
                                      key[0], blo[0], bhi[0], sx, sy, sz, last, wmax, wmax_j);
     }
     for (int k = k0;; ++k) {
@@ -773,7 +800,8 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
             int r0[G];
 #pragma unroll
-            for (int u = 0; u < G; ++u) r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS;
+            for (int u = 0; u < G; ++u)                         // BH = 2: slots 2p and 2p+1 are the halves of one bucket
+                r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (BH == 2 ? (u & 1) * 64 : 0);
             unsigned long long bk[G];
             float4 bp[G];
             const int nchunks = MULTI ? chunks : 1;
@@ -814,12 +842,27 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             unsigned long long wk[G];
             int src[G];
             wave_argmax_key_x<G>(bk, wk, src);
+            if constexpr (BH == 2 && G < 2) {
+                // never called: halved buckets occupy slot pairs
+            } else if constexpr (BH == 2) {
 #pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int j = (s_idx * 64 + ol[u]) * NW + wave;
-                if (lane == src[u]) bxyz[j] = bp[u];
-                if (lane == ol[u]) key_s = wk[u];
-                if (wk[u] > cand) { cand = wk[u]; cand_j = j; }          // scalar
+                for (int q = 0; q < G; q += 2) {                // the bucket's key is the larger of its halves' keys
+                    const int j = (s_idx * 64 + ol[q]) * NW + wave;
+                    const bool hi = wk[q + 1] > wk[q];          // scalar
+                    const unsigned long long wb = hi ? wk[q + 1] : wk[q];
+                    if (hi) { if (lane == src[q + 1]) bxyz[j] = bp[q + 1]; }
+                    else { if (lane == src[q]) bxyz[j] = bp[q]; }
+                    if (lane == ol[q]) key_s = wb;
+                    if (wb > cand) { cand = wb; cand_j = j; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int j = (s_idx * 64 + ol[u]) * NW + wave;
+                    if (lane == src[u]) bxyz[j] = bp[u];
+                    if (lane == ol[u]) key_s = wk[u];
+                    if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
+                }
             }
 #ifdef PCP_FPS_STAMPS
             { unsigned long long tb; STAMP(tb); sRed += tb - tc0; }
@@ -832,10 +875,19 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             unsigned long long m = amask[s];
             while (m) {                                         // wave-uniform
                 int ol[4], n = 0;
+                if constexpr (BH == 2) {                        // two buckets per pass, two slots each
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                   // a fourth slot left over repeats slot 0: harmless
-                    if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
-                    else ol[u] = ol[0];
+                    for (int u = 0; u < 4; u += 2) {
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 2; }
+                        else ol[u] = ol[0];
+                        ol[u + 1] = ol[u];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {               // a fourth slot left over repeats slot 0: harmless
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                        else ol[u] = ol[0];
+                    }
                 }
 #ifdef PCP_FPS_STAMPS
                 sPass += 1; sAct += n;
@@ -897,13 +949,13 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
 // "wide" shape (single-chunk buckets): two workgroups of 1024 (four of 512) per CU, so every frame of a
 // 300-frame batch is resident at once.  8 waves/SIMD need <= 64 VGPRs and <= 80 SGPRs per wave (800 per
 // SIMD, allocated 16 + 16k); the caps are explicit because __launch_bounds__ alone does not enforce them.
-template <int T, int CPL, int MODE>
+template <int T, int CPL, int MODE, int BH = 1>
 __global__ void __launch_bounds__(T, 2048 / T) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
 fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                 float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
 {
-    fps_bucket_body<T, CPL, false, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
+    fps_bucket_body<T, CPL, false, MODE, BH>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
 }
 
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
@@ -937,14 +989,14 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
 // multiple of 64 rows, for larger clouds.  The host only knows an upper bound on the cloud sizes,
 // so when that bound exceeds 65,536 both shapes are launched and every workgroup keeps or drops
 // its cloud by its actual size (a dropped workgroup exits at once).
-template <int T, int CPL, bool MULTI, int MODE>
+template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const float* xyz, const long long* offsets, int B, int K, long long* idx,
                             float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, int lazy, hipStream_t st)
 {
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
-    else kern = fps_bucket_wide<T, CPL, MODE>;
+    else kern = fps_bucket_wide<T, CPL, MODE, BH>;
     // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
     // (lazy: 0 = by batch size, 1 = always, -1 = never)
     const int lazy_k = (!MULTI && CPL == 1 && lazy >= 0 && (lazy > 0 || B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;
@@ -972,13 +1024,17 @@ static int launch_bucket(const float* xyz, const long long* offsets, int B, int6
     int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
                                                           PCP_FPS_WIDE_MAX, lazy, st);
     if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
-    // large clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
+    // up to 131,072 points: the same shape with buckets of two 64-row halves, streamed side by side
+    rc = launch_bucket_as<1024, 1, false, MODE, 2>(xyz, offsets, B, K, idx, out_xyz, pts4, md, PCP_FPS_WIDE_MAX + 1,
+                                                   2 * PCP_FPS_WIDE_MAX, lazy, st);
+    if (rc != PCP_OK || max_pts <= 2 * PCP_FPS_WIDE_MAX) return rc;
+    // larger clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
     // twice the waves streaming and half the rows per bucket; bigger batches keep two 512-thread workgroups per CU
     if (B <= PCP_FPS_DEEP_1024_MAX_B)
         return launch_bucket_as<1024, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                            PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
+                                                            2 * PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
     return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                       PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
+                                                       2 * PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
 }
 
 extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,

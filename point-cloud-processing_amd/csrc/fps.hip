@@ -537,7 +537,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             float mm[G];
 #pragma unroll
             for (int u = 0; u < G; ++u) {
-                r0[u] = (ol[u] * NW + wave) * BS + (BH == 2 ? (u & 1) * 64 : 0);     // BH = 2: slots 2p, 2p+1 = one bucket's halves
+                r0[u] = (ol[u] * NW + wave) * BS + (u % BH) * 64;                     // BH > 1: BH consecutive slots = one bucket's parts
                 if (FULL) {
                     pt[u] = (S + r0[u])[lane];
                     mm[u] = (D + r0[u])[lane];
@@ -576,16 +576,20 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             unsigned long long wk[G];
             int src[G];
             wave_argmax_key_x<G>(bk, wk, src);
-            if constexpr (BH == 2 && G < 2) {
-                // never called: halved buckets occupy slot pairs
-            } else if constexpr (BH == 2) {
+            if constexpr (BH > 1 && G < BH) {
+                // never called: a split bucket occupies BH slots
+            } else if constexpr (BH > 1) {
 #pragma unroll
-                for (int q = 0; q < G; q += 2) {
+                for (int q = 0; q < G; q += BH) {               // the bucket's key is the largest of its parts' keys
                     const int j = ol[q] * NW + wave;
-                    const bool hi = wk[q + 1] > wk[q];          // scalar
-                    const unsigned long long wb = hi ? wk[q + 1] : wk[q];
-                    if (hi) { if (lane == src[q + 1]) bxyz[j] = pt[q + 1]; }
-                    else { if (lane == src[q]) bxyz[j] = pt[q]; }
+                    int w = q;                                  // scalar
+                    unsigned long long wb = wk[q];
+#pragma unroll
+                    for (int h = 1; h < BH; ++h)
+                        if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
+#pragma unroll
+                    for (int h = 0; h < BH; ++h)
+                        if (w == q + h && lane == src[q + h]) bxyz[j] = pt[q + h];
                     if (lane == ol[q]) { key = wb; pend = 0u; }
                     if (wb > cand) { cand = wb; cand_j = j; }
                 }
@@ -605,12 +609,13 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
             unsigned long long m = amask;
             while (m) {                                         // wave-uniform
                 int ol[4], n = 0;
-                if constexpr (BH == 2) {
+                if constexpr (BH > 1) {
 #pragma unroll
-                    for (int u = 0; u < 4; u += 2) {
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 2; }
+                    for (int u = 0; u < 4; u += BH) {
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + BH; }
                         else ol[u] = ol[0];
-                        ol[u + 1] = ol[u];
+#pragma unroll
+                        for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
                     }
                 } else {
 #pragma unroll
@@ -707,9 +712,9 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
 
     // ---- prologue 3: buckets and their owners ---------------------------------------------------------
     // 64-row chunks per bucket; the single-chunk shape is only launched for clouds of <= 64·NBMAX points
-    // (BH = 2, single-chunk shape only: buckets of two 64-row halves that are streamed side by side, for clouds of
-    //  up to 128·NBMAX points)
-    static_assert(BH == 1 || (BH == 2 && !MULTI && CPL == 1), "halved buckets are a variant of the wide shape");
+    // (BH = 2 or 4, single-chunk shape only: buckets of BH 64-row parts that are streamed side by side, for clouds
+    //  of up to 64·BH·NBMAX points)
+    static_assert(BH == 1 || ((BH == 2 || BH == 4) && !MULTI && CPL == 1), "split buckets are a variant of the wide shape");
     const int chunks = MULTI ? (M + 64 * NBMAX - 1) / (64 * NBMAX) : 1;
     const int BS = 64 * chunks * BH;
     const int NB = (M + BS - 1) / BS;
@@ -800,8 +805,8 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
             int r0[G];
 #pragma unroll
-            for (int u = 0; u < G; ++u)                         // BH = 2: slots 2p and 2p+1 are the halves of one bucket
-                r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (BH == 2 ? (u & 1) * 64 : 0);
+            for (int u = 0; u < G; ++u)                         // BH > 1: BH consecutive slots are the parts of one bucket
+                r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (u % BH) * 64;
             unsigned long long bk[G];
             float4 bp[G];
             const int nchunks = MULTI ? chunks : 1;
@@ -842,16 +847,20 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             unsigned long long wk[G];
             int src[G];
             wave_argmax_key_x<G>(bk, wk, src);
-            if constexpr (BH == 2 && G < 2) {
-                // never called: halved buckets occupy slot pairs
-            } else if constexpr (BH == 2) {
+            if constexpr (BH > 1 && G < BH) {
+                // never called: a split bucket occupies BH slots
+            } else if constexpr (BH > 1) {
 #pragma unroll
-                for (int q = 0; q < G; q += 2) {                // the bucket's key is the larger of its halves' keys
+                for (int q = 0; q < G; q += BH) {               // the bucket's key is the largest of its parts' keys
                     const int j = (s_idx * 64 + ol[q]) * NW + wave;
-                    const bool hi = wk[q + 1] > wk[q];          // scalar
-                    const unsigned long long wb = hi ? wk[q + 1] : wk[q];
-                    if (hi) { if (lane == src[q + 1]) bxyz[j] = bp[q + 1]; }
-                    else { if (lane == src[q]) bxyz[j] = bp[q]; }
+                    int w = q;                                  // scalar
+                    unsigned long long wb = wk[q];
+#pragma unroll
+                    for (int h = 1; h < BH; ++h)
+                        if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
+#pragma unroll
+                    for (int h = 0; h < BH; ++h)
+                        if (w == q + h && lane == src[q + h]) bxyz[j] = bp[q + h];
                     if (lane == ol[q]) key_s = wb;
                     if (wb > cand) { cand = wb; cand_j = j; }
                 }
@@ -875,12 +884,13 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             unsigned long long m = amask[s];
             while (m) {                                         // wave-uniform
                 int ol[4], n = 0;
-                if constexpr (BH == 2) {                        // two buckets per pass, two slots each
+                if constexpr (BH > 1) {                         // 4 / BH buckets per pass, BH slots each
 #pragma unroll
-                    for (int u = 0; u < 4; u += 2) {
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 2; }
+                    for (int u = 0; u < 4; u += BH) {
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + BH; }
                         else ol[u] = ol[0];
-                        ol[u + 1] = ol[u];
+#pragma unroll
+                        for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
                     }
                 } else {
 #pragma unroll
@@ -1010,6 +1020,9 @@ static int launch_bucket_as(const float* xyz, const long long* offsets, int B, i
 #define PCP_FPS_SHAPE 0          // 0: wide for small clouds + deep for large; 2: deep only (tuning builds)
 #endif
 #define PCP_FPS_WIDE_MAX (64 * 1024)
+#ifndef PCP_FPS_SPLIT4
+#define PCP_FPS_SPLIT4 1         // 0: clouds above 131,072 points go to the deep shape (tuning builds)
+#endif
 #ifndef PCP_FPS_DEEP_1024_MAX_B
 #define PCP_FPS_DEEP_1024_MAX_B 256
 #endif
@@ -1024,17 +1037,23 @@ static int launch_bucket(const float* xyz, const long long* offsets, int B, int6
     int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
                                                           PCP_FPS_WIDE_MAX, lazy, st);
     if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
-    // up to 131,072 points: the same shape with buckets of two 64-row halves, streamed side by side
+    // up to 131,072 / 262,144 points: the same shape with buckets of two / four 64-row parts, streamed side by side
     rc = launch_bucket_as<1024, 1, false, MODE, 2>(xyz, offsets, B, K, idx, out_xyz, pts4, md, PCP_FPS_WIDE_MAX + 1,
                                                    2 * PCP_FPS_WIDE_MAX, lazy, st);
     if (rc != PCP_OK || max_pts <= 2 * PCP_FPS_WIDE_MAX) return rc;
+    constexpr int split_max = PCP_FPS_SPLIT4 ? 4 * PCP_FPS_WIDE_MAX : 2 * PCP_FPS_WIDE_MAX;
+    if (PCP_FPS_SPLIT4) {
+        rc = launch_bucket_as<1024, 1, false, MODE, 4>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
+                                                       2 * PCP_FPS_WIDE_MAX + 1, 4 * PCP_FPS_WIDE_MAX, lazy, st);
+        if (rc != PCP_OK || max_pts <= 4 * PCP_FPS_WIDE_MAX) return rc;
+    }
     // larger clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
     // twice the waves streaming and half the rows per bucket; bigger batches keep two 512-thread workgroups per CU
     if (B <= PCP_FPS_DEEP_1024_MAX_B)
         return launch_bucket_as<1024, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                            2 * PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
+                                                            split_max + 1, 0x7fffffff, lazy, st);
     return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                       2 * PCP_FPS_WIDE_MAX + 1, 0x7fffffff, lazy, st);
+                                                       split_max + 1, 0x7fffffff, lazy, st);
 }
 
 extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,

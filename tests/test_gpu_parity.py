@@ -324,7 +324,7 @@ def test_fps_deferred_rounds_hand_over_to_the_eager_loop(dist_mode):
     """algo 3 runs the first 256 rounds with deferred bucket updates, drains the pending lists and continues with
     the eager loop: K just below, at and above the hand-over, and clouds whose size ends the rounds before it."""
     rng = np.random.default_rng(27)
-    sizes = [60000, 255, 256, 257, 258, 300, 5000, 64, 4096, 70001, 131072, 131073]   # incl. both halved-bucket bounds and one deep cloud
+    sizes = [60000, 255, 256, 257, 258, 300, 5000, 64, 4096, 70001, 131072, 131073, 262144, 262145]   # incl. the split-bucket shapes' bounds and one deep cloud
     clouds = [(rng.normal(0, 0.3, (m, 3)) * np.array([1.0, 0.7, 0.1])).astype(np.float32) for m in sizes]
     for K in (255, 256, 257, 258, 700):
         xyz, idx = run_fps(clouds, K, dist_mode, 3)

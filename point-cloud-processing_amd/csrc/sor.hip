@@ -18,6 +18,9 @@
 #include <float.h>
 
 #define SOR_RMAX 3
+#ifndef SOR_RSTART
+#define SOR_RSTART 1
+#endif
 
 __global__ void __launch_bounds__(256)
 sor_gather_sorted(const double* __restrict__ xyz, const unsigned int* __restrict__ vals,
@@ -75,7 +78,7 @@ template <int KCAP>
 __global__ void __launch_bounds__(256, 1)
 sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
         const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
-        int nb, double* __restrict__ avg)
+        int nb, const unsigned long long* __restrict__ minb, double* __restrict__ avg)
 {
     __shared__ double queue[SOR_Q * 256];
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,6 +91,10 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
     const int k = (long long)nb < M ? nb : (int)M;
     const double px = sxyz[3 * j], py = sxyz[3 * j + 1], pz = sxyz[3 * j + 2];
     const unsigned long long cloud = (unsigned long long)b << 48;
+    // grid origin exactly as vox_keys computes it, and a slack that covers the rounding of the cell-index division
+    // there (a few ulps of the coordinates): row (x,y) holds no point closer to p than the gap computed below
+    const double ox = vox_unord(minb[3 * b]) - cell * 0.5, oy = vox_unord(minb[3 * b + 1]) - cell * 0.5;
+    const double slack = 1e-9 * cell + 1e-14 * (fabs(px) + fabs(py) + fabs(ox) + fabs(oy) + 65536.0 * cell);
     double* q = queue + threadIdx.x;        // this lane's queue: q[slot * 256]
     double best[KCAP];
     double tau = DBL_MAX;                   // candidates >= tau cannot enter the k best (stale between drains: only larger)
@@ -111,7 +118,7 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
     };
     bool done = false;
     if (M > k) {
-        for (int r = 1; r <= SOR_RMAX && !done; ++r) {
+        for (int r = SOR_RSTART; r <= SOR_RMAX && !done; ++r) {
             reset();
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > 65535 ? 65535 : cz + r;
             // rows nearest the query's own row first (offsets 0,-1,+1,-2,+2,...): the bound tightens early and
@@ -119,9 +126,15 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
             for (int ix = 0; ix <= 2 * r; ++ix) {
                 const int x = cx + ((ix & 1) ? -((ix + 1) >> 1) : (ix >> 1));
                 if (x < 0 || x > 65535) continue;
+                double gx = x > cx ? (ox + (double)x * cell) - px : (x < cx ? px - (ox + (double)(x + 1) * cell) : 0.0);
+                gx = gx > slack ? gx - slack : 0.0;
+                if (gx * gx >= tau) continue;                            // the whole x slab is farther than the k-th best
                 for (int iy = 0; iy <= 2 * r; ++iy) {                    // one contiguous key run per (x,y) row
                     const int y = cy + ((iy & 1) ? -((iy + 1) >> 1) : (iy >> 1));
                     if (y < 0 || y > 65535) continue;
+                    double gy = y > cy ? (oy + (double)y * cell) - py : (y < cy ? py - (oy + (double)(y + 1) * cell) : 0.0);
+                    gy = gy > slack ? gy - slack : 0.0;
+                    if (gx * gx + gy * gy >= tau) continue;              // no point of this row can enter the k best
                     const unsigned long long row = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y << 16);
                     const unsigned long long k1 = row | (unsigned long long)z1;
                     for (long long t = sor_lower_bound(keys, lo, hi, row | (unsigned long long)z0); t < hi; ++t) {
@@ -322,15 +335,15 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
                                           64u, st));
     hipLaunchKernelGGL(sor_gather_sorted, dim3(nblk), dim3(256), 0, st, xyz, vals_out, off, B, sxyz);
     if (nb_neighbors <= 8)
-        hipLaunchKernelGGL(sor_knn<8>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+        hipLaunchKernelGGL(sor_knn<8>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
     else if (nb_neighbors <= 16)
-        hipLaunchKernelGGL(sor_knn<16>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+        hipLaunchKernelGGL(sor_knn<16>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
     else if (nb_neighbors <= 20)
-        hipLaunchKernelGGL(sor_knn<20>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+        hipLaunchKernelGGL(sor_knn<20>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
     else if (nb_neighbors <= 24)
-        hipLaunchKernelGGL(sor_knn<24>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+        hipLaunchKernelGGL(sor_knn<24>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
     else
-        hipLaunchKernelGGL(sor_knn<32>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, avg);
+        hipLaunchKernelGGL(sor_knn<32>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
     hipLaunchKernelGGL(sor_stats, dim3(B), dim3(64), 0, st, avg, off, std_ratio, stats);
     hipLaunchKernelGGL(sor_flags, dim3(tiles), dim3(256), 0, st, avg, off, B, stats, masks, tile_cnt);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);

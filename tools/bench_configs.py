@@ -33,7 +33,7 @@ def config3(B):
     f1(); M = int(st["off"][-1].item())
     def f2(): st["v"], st["voff"] = ops.voxel_downsample(st["o"]["xyz64"], st["o"]["rgb32"], st["off"], 0.005, cap_pts=M)
     f2(); V = int(st["voff"][-1].item())
-    st["cell"] = ops.sor_cell_size(st["v"]["xyz64"][:V], B, 20)
+    st["cell"] = ops.sor_cell_size(st["v"]["xyz64"][:V], B, 20) * float(os.environ.get("PCP_SOR_CELL_SCALE", "1"))
     def f3(): st["s"], st["soff"] = ops.statistical_outlier_removal(st["v"]["xyz64"], st["v"]["rgb32"], st["voff"], 20, 2.0, st["cell"], cap_pts=V)
     f3(); S = int(st["soff"][-1].item())
     mx = int((st["soff"][1:] - st["soff"][:-1]).max().item())

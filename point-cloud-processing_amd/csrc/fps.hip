@@ -994,11 +994,11 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
 }
 
-// Launch shapes.  "wide": 16 waves, one 64-row bucket per lane, for clouds of up to 65,536 points
-// (the 640x480 workspace-cropped case); "deep": 8 waves, two buckets per lane, buckets of any
-// multiple of 64 rows, for larger clouds.  The host only knows an upper bound on the cloud sizes,
-// so when that bound exceeds 65,536 both shapes are launched and every workgroup keeps or drops
-// its cloud by its actual size (a dropped workgroup exits at once).
+// Launch shapes.  "wide": 16 waves, one bucket per lane — 64 rows for clouds of up to 65,536 points (the 640x480
+// workspace-cropped case), 128 / 256 rows in two / four parts (BH) up to 131,072 / 262,144 points; "deep": two
+// buckets per lane, buckets of any multiple of 64 rows, beyond that.  The host only knows an upper bound on the
+// cloud sizes, so every shape the bound allows is launched and every workgroup keeps or drops its cloud by its
+// actual size (a dropped workgroup exits at once).
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const float* xyz, const long long* offsets, int B, int K, long long* idx,
                             float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, int lazy, hipStream_t st)

@@ -178,10 +178,12 @@ __device__ __forceinline__ void wave_argmax_key_x(const unsigned long long (&k)[
     }
 }
 
-// arg-max over the keys held by lanes 0..N-1 (N = 4, 8 or 16; other lanes must hold 0)
+// arg-max over the keys held by lanes 0..N-1 (N = 4, 8 or 16).  The reduction stays inside row 0 and the ballots
+// are masked to the low N lanes, so the other lanes may hold anything (no exec masking around the loads).
 template <int N>
 __device__ __forceinline__ unsigned long long lowlanes_argmax_key(unsigned long long k, int* src)
 {
+    constexpr unsigned long long LOW = (1ull << N) - 1ull;
     unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
     unsigned m = hi;
     m = max(m, dpp_u32<0xB1>(m));
@@ -189,7 +191,7 @@ __device__ __forceinline__ unsigned long long lowlanes_argmax_key(unsigned long 
     if (N > 4) m = max(m, dpp_u32<0x141>(m));
     if (N > 8) m = max(m, dpp_u32<0x140>(m));
     m = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
-    unsigned long long hit = __ballot(hi == m);
+    unsigned long long hit = __ballot(hi == m) & LOW;
     unsigned l;
     if (__popcll(hit) == 1) {
         *src = __ffsll((long long)hit) - 1;
@@ -201,7 +203,7 @@ __device__ __forceinline__ unsigned long long lowlanes_argmax_key(unsigned long 
         if (N > 4) t = max(t, dpp_u32<0x141>(t));
         if (N > 8) t = max(t, dpp_u32<0x140>(t));
         l = (unsigned)__builtin_amdgcn_readlane((int)t, 0);
-        hit = __ballot(hi == m && lo == l);
+        hit = __ballot(hi == m && lo == l) & LOW;
         *src = __ffsll((long long)hit) - 1;
     }
     return ((unsigned long long)m << 32) | l;
@@ -645,7 +647,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
         if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // see the eager loop
         {
-            const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
+            const unsigned long long kk = pkey[par * NW + (lane & (NW - 1))];
             const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
             int src;
             const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
@@ -934,7 +936,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         {
             // every low lane fetches its wave's key AND xyz in one LDS round trip; the winner's xyz is then a
             // readlane away instead of a second, dependent LDS read
-            const unsigned long long kk = lane < NW ? pkey[par * NW + lane] : 0ull;
+            const unsigned long long kk = pkey[par * NW + (lane & (NW - 1))];
             const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
             int src;
             const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);

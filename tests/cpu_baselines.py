@@ -2,7 +2,7 @@
 """CPU baselines beside the GPU number: the op-for-op numpy restatement and the C oracle of the
 per-frame path (640x480 -> crop -> 1024-pt FPS) on this box's host cores — one process, and one process per
 core of the box's CPU share — compute-only and with the PLY round trip the reference's stages perform.
-Test infrastructure only (imports oracle/).    python3 tools/cpu_baselines.py [--procs 16] [--frames 8]"""
+Test infrastructure (it imports oracle/, which is why it lives under tests/; pytest does not collect it).    python3 tests/cpu_baselines.py [--procs 16] [--frames 8]"""
 import argparse, json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]

@@ -79,3 +79,10 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f"{fn} mentions the oracle"
+    # tools/ and examples/ are developer programs around the product: they may not use the checker either
+    for sub in ("tools", "examples"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, sub)):
+            for fn in fns:
+                if fn.endswith((".py", ".sh", ".c", ".h")):
+                    src = open(os.path.join(dp, fn)).read()
+                    assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f"{sub}/{fn} uses oracle/"

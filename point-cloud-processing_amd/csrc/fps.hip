@@ -423,7 +423,17 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
 #ifdef PCP_FPS_STAMPS
     STAMP(q2);
 #endif
-    for (int p = tid; p < M; p += T) D[p] = FLT_MAX;            // coalesced fill instead of a scattered one
+    {
+        // coalesced fill instead of a scattered one, 16 bytes per lane where D allows it (D is only 4-byte aligned:
+        // head and tail go by single floats) — a quarter of the store instructions of a float-per-lane loop
+        const int head = min(M, (int)((16u - ((unsigned)(uintptr_t)D & 15u)) & 15u) >> 2);
+        const int body = (M - head) >> 2;
+        if (tid < head) D[tid] = FLT_MAX;
+        float4* D4 = (float4*)(D + head);
+        for (int p = tid; p < body; p += T) D4[p] = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX);
+        const int done = head + 4 * body;
+        if (tid < M - done) D[done + tid] = FLT_MAX;
+    }
     for (int p0 = tid; p0 < M; p0 += T * PU) {
         float v[PU][3];
         int pos[PU];

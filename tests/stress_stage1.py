@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Randomised stage-1 parity soak (not collected by pytest; run by hand on a GPU box):
+   python tests/stress_stage1.py [--seconds 120] [--seed 0]
+Random image sizes (depth and colour differ), intrinsics, depth->colour and camera->base transforms, workspaces,
+crop on/off, fused/unfused transform, and depth images with zeros, negatives, NaN and inf: every output of the fused
+backproject/align/crop entry point must equal the C oracle bit for bit, rows in pixel order."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]
+import numpy as np, torch
+from oracle import cbind
+from pcp import _ffi, ops
+
+
+def rot(rng):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    return q * np.sign(np.linalg.det(q))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    t_end, n = time.time() + a.seconds, 0
+    while time.time() < t_end:
+        H, W = int(rng.integers(1, 200)), int(rng.integers(1, 260))
+        Hc, Wc = (H, W) if rng.random() < 0.5 else (int(rng.integers(1, 300)), int(rng.integers(1, 300)))
+        B = int(rng.integers(1, 5))
+        f = float(rng.uniform(20, 900))
+        dintr = dict(fx=f, fy=f * rng.uniform(0.9, 1.1), cx=W / 2 + rng.uniform(-3, 3), cy=H / 2 + rng.uniform(-3, 3))
+        cintr = dict(fx=f * Wc / W, fy=f * Hc / H * rng.uniform(0.9, 1.1), cx=Wc / 2 + rng.uniform(-3, 3), cy=Hc / 2 + rng.uniform(-3, 3))
+        T = np.eye(4); T[:3, 3] = rng.uniform(-0.08, 0.08, 3)
+        if rng.random() < 0.3:
+            T[:3, :3] = rot(rng) if rng.random() < 0.2 else np.eye(3) + 0.01 * rng.standard_normal((3, 3))
+        E = np.eye(4); E[:3, :3] = rot(rng); E[:3, 3] = rng.uniform(-1, 1, 3)
+        c0 = E[:3, :3] @ np.array([0, 0, rng.uniform(0.4, 1.2)]) + E[:3, 3]      # a workspace around where the camera looks
+        half = rng.uniform(0.05, 0.8, 3)
+        ws = tuple((float(c0[i] - half[i]), float(c0[i] + half[i])) for i in range(3))
+        crop, fma = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        depth = (rng.integers(0, 2500, (B, H, W)).astype(np.float32) / 1000).astype(np.float32)
+        bad = rng.random((B, H, W))
+        depth[bad < 0.05] = 0.0
+        depth[(bad >= 0.05) & (bad < 0.06)] = np.nan
+        depth[(bad >= 0.06) & (bad < 0.07)] = np.inf
+        depth[(bad >= 0.07) & (bad < 0.08)] = -0.5
+        depth[(bad >= 0.08) & (bad < 0.09)] = 6.0
+        rgb = rng.integers(0, 256, (B, Hc, Wc, 3), dtype=np.uint8)
+        p = _ffi.make_params(dintr, cintr, T=T, ext=E, workspace=ws, apply_crop=crop, transform_fma=fma)
+        po = cbind.make_params(dintr, cintr, T=T, ext=E, ws=ws, apply_crop=int(crop), transform_fma=int(fma))
+        s1 = ops.Stage1(B, H, W, "cuda", want=("xyz_cam64", "xyz64", "xyz32", "rgb32", "pix"))   # Hc, Wc come from rgb
+        out, off = s1.run(torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda(), p)
+        off = off.cpu().numpy()
+        for b in range(B):
+            ref = cbind.backproject_align_crop(depth[b], rgb[b], po)
+            sl = slice(off[b], off[b + 1])
+            for k in ("pix", "xyz_cam64", "xyz64", "xyz32", "rgb32"):
+                got = out[k][sl].cpu().numpy()
+                if got.shape != ref[k].shape or not np.array_equal(got, ref[k], equal_nan=True):
+                    print(f"MISMATCH seed={a.seed} case={n} frame={b} field={k} H={H} W={W} Hc={Hc} Wc={Wc} crop={crop} fma={fma}", flush=True)
+                    sys.exit(1)
+        n += 1
+        if n % 50 == 0:
+            print(f"{n} cases ok", flush=True)
+    print(f"done: {n} random cases, all bit-exact", flush=True)
+
+
+if __name__ == "__main__":
+    main()

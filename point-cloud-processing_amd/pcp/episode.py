@@ -12,7 +12,8 @@ from . import _ffi, ops
 
 
 class EpisodeRunner:
-    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=0, Hc=None, Wc=None, depth_mm=False):
+    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=0, Hc=None, Wc=None, depth_mm=False,
+                 stage_threads=8, upload_piece=25):
         if not torch.cuda.is_available():
             raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
         self.H, self.W, self.K, self.params, self.chunk = H, W, K, params, int(chunk)
@@ -33,18 +34,45 @@ class EpisodeRunner:
         self.h_rows = mk((self.chunk, K, 6), torch.float32)
         self.h_off = mk((self.chunk + 1,), torch.int64)
         self.done = torch.cuda.Event()
+        self.stage_threads = max(1, int(stage_threads))
+        self.upload_piece = int(upload_piece)                # frames per staging/DMA piece
+        self._pool = ThreadPoolExecutor(max_workers=self.stage_threads) if self.stage_threads > 1 else None
+
+    def _stage(self, dst, src):
+        """pageable → pinned copy of the first len(src) frames, split over the staging threads (numpy releases the
+        GIL inside copyto; one memcpy thread does not saturate the host memory system)."""
+        n = src.shape[0]
+        view = dst.numpy()
+        parts = min(self.stage_threads, n)
+        if parts <= 1:
+            np.copyto(view[:n], src)
+            return
+        cuts = [n * i // parts for i in range(parts + 1)]
+        list(self._pool.map(lambda ab: np.copyto(view[ab[0]:ab[1]], src[ab[0]:ab[1]]), zip(cuts[:-1], cuts[1:])))
 
     def _upload(self, slot, depth, rgb):
+        """Stage + upload one chunk in pieces: while the DMA engine moves piece i, the host threads stage piece
+        i+1 into the pinned buffer, so staging and the PCIe transfer overlap instead of adding up."""
         n = depth.shape[0]
-        self.h_depth[slot][:n].copy_(torch.from_numpy(depth))
-        self.h_rgb[slot][:n].copy_(torch.from_numpy(rgb))
         if n < self.chunk:                                   # a short tail chunk: invalid depth → empty clouds
             self.h_depth[slot][n:].zero_()
+        piece = max(1, self.upload_piece)
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.consumed[slot])
-            self.d_depth[slot].copy_(self.h_depth[slot], non_blocking=True)
-            self.d_rgb[slot].copy_(self.h_rgb[slot], non_blocking=True)
-            self.uploaded[slot].record(self.copy_stream)
+        for a in range(0, max(n, 1), piece):
+            b = min(a + piece, n)
+            if b > a:
+                self._stage(self.h_depth[slot][a:b], depth[a:b])
+                self._stage(self.h_rgb[slot][a:b], rgb[a:b])
+            last = b >= n
+            hi = self.chunk if last else b                   # the last piece carries the zeroed tail too
+            with torch.cuda.stream(self.copy_stream):
+                self.d_depth[slot][a:hi].copy_(self.h_depth[slot][a:hi], non_blocking=True)
+                self.d_rgb[slot][a:hi].copy_(self.h_rgb[slot][a:hi], non_blocking=True)
+                if last:
+                    self.uploaded[slot].record(self.copy_stream)
+            if last:
+                break
 
     def run_chunks(self, chunks):
         """chunks: iterable of (depth (n,H,W) f32, rgb (n,Hc,Wc,3) u8) with n <= chunk.

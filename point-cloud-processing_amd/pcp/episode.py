@@ -38,12 +38,24 @@ class EpisodeRunner:
         self.upload_piece = int(upload_piece)                # frames per staging/DMA piece
         self._pool = ThreadPoolExecutor(max_workers=self.stage_threads) if self.stage_threads > 1 else None
 
+    def close(self):
+        """Stop the staging threads (also called when the runner is garbage-collected)."""
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _stage(self, dst, src):
         """pageable → pinned copy of the first len(src) frames, split over the staging threads (numpy releases the
         GIL inside copyto; one memcpy thread does not saturate the host memory system)."""
         n = src.shape[0]
         view = dst.numpy()
-        parts = min(self.stage_threads, n)
+        parts = min(self.stage_threads, n) if self._pool is not None else 1
         if parts <= 1:
             np.copyto(view[:n], src)
             return

@@ -31,20 +31,25 @@ int main(int argc, char** argv)
     const int64_t h_off[2] = {0, M};
     float *d_xyz, *d_out;
     int64_t *d_off, *d_idx;
+    int32_t* d_flag;
     void* d_ws;
     const size_t ws_bytes = pcp_fps_workspace_bytes(1, M, M, K, 0);
     HIP_OK(hipMalloc((void**)&d_xyz, (size_t)M * 12));
     HIP_OK(hipMalloc((void**)&d_off, sizeof h_off));
     HIP_OK(hipMalloc((void**)&d_idx, (size_t)K * 8));
     HIP_OK(hipMalloc((void**)&d_out, (size_t)K * 12));
+    HIP_OK(hipMalloc((void**)&d_flag, sizeof(int32_t)));
     HIP_OK(hipMalloc(&d_ws, ws_bytes));                       /* hipMalloc returns >= 256-byte aligned memory */
     HIP_OK(hipMemcpy(d_xyz, h_xyz, (size_t)M * 12, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_off, h_off, sizeof h_off, hipMemcpyHostToDevice));
 
-    const int rc = pcp_fps_batched(d_xyz, d_off, 1, M, M, K, /*dist_mode*/ 0, /*algo*/ 0, d_idx, d_out, d_ws, ws_bytes,
-                                   /*stream*/ NULL);
+    const int rc = pcp_fps_batched(d_xyz, d_off, 1, M, M, K, /*dist_mode*/ 0, /*algo*/ 0, d_idx, d_out, d_flag, d_ws,
+                                   ws_bytes, /*stream*/ NULL);
     if (rc != PCP_OK) { fprintf(stderr, "pcp_fps_batched: %s\n", pcp_strerror(rc)); return 3; }
     HIP_OK(hipDeviceSynchronize());
+    int32_t h_flag = 0;
+    HIP_OK(hipMemcpy(&h_flag, d_flag, sizeof h_flag, hipMemcpyDeviceToHost));
+    if (h_flag) { fprintf(stderr, "pcp_fps_batched: a cloud exceeded max_pts / total_pts\n"); return 4; }
 
     int64_t* h_idx = (int64_t*)malloc((size_t)K * 8);
     HIP_OK(hipMemcpy(h_idx, d_idx, (size_t)K * 8, hipMemcpyDeviceToHost));
@@ -53,7 +58,7 @@ int main(int argc, char** argv)
     fclose(f);
     printf("first picks: %lld %lld %lld %lld\n", (long long)h_idx[0], (long long)h_idx[K > 1], (long long)h_idx[K > 2 ? 2 : 0],
            (long long)h_idx[K > 3 ? 3 : 0]);
-    hipFree(d_xyz); hipFree(d_off); hipFree(d_idx); hipFree(d_out); hipFree(d_ws);
+    hipFree(d_xyz); hipFree(d_off); hipFree(d_idx); hipFree(d_out); hipFree(d_flag); hipFree(d_ws);
     free(h_xyz); free(h_idx);
     return 0;
 }

@@ -18,8 +18,12 @@
  *     *_workspace_bytes query.  Workspaces must be 256-byte aligned.
  *   - Return value: 0 = PCP_OK, negative = pcp_status.  No exception or abort
  *     crosses the ABI.  pcp_strerror() gives a static message.
- *   - No global mutable state: calls on different streams / workspaces are
- *     independent and thread-safe.
+ *   - Devices: kernels are launched on the CURRENT HIP device.  On a multi-GPU host the caller makes
+ *     the device that owns `stream` and the buffers current (hipSetDevice / torch.cuda.device)
+ *     before the call; the library never changes the current device.
+ *   - No mutable state is shared between calls: calls on different streams / workspaces are
+ *     independent and thread-safe.  (One process-wide footnote: the FPS shapes that need more than
+ *     48 KB of LDS set that per-kernel attribute, to the same value, on every launch.)
  */
 #ifndef PCP_H
 #define PCP_H
@@ -71,7 +75,7 @@ typedef struct {
 void pcp_default_params(pcp_params* p);
 
 const char* pcp_strerror(int status);
-/* Library version string, e.g. "pcp-hip 0.1 gfx950". */
+/* Library version string, e.g. "pcp-hip 0.2 gfx950". */
 const char* pcp_version(void);
 /* Number of visible HIP devices (0 on a CPU-only host; never fails). */
 int pcp_device_count(void);
@@ -212,26 +216,37 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *                rounds defer bucket updates when the batch is large enough for that to pay
  *             3: as 2 with the deferred rounds always on   4: as 2 with them always off
  *                (same indices either way; for tests and tuning)
- * `max_pts` is an upper bound on the largest cloud (host-known, e.g. H*W); it
- * sizes the launch, not the result.
+ * `total_pts` is the row count of xyz (and of the workspace).  `max_pts` is an upper bound on the
+ * largest cloud (host-known, e.g. H*W): it decides which size-bucketed launch shapes run, never
+ * the picks.
  * Ties are broken toward the lowest index; idx[b][0] = 0.  Empty clouds give
  * an all -1 row (the reference raises inside pytorch3d; the Python wrapper
  * raises too).
+ * `overflow` (device i32, may be NULL) is cleared by the call and set to 1 by the kernels when a
+ * cloud could not be sampled: more points than `max_pts` promised (beyond the shapes that were
+ * launched), or rows outside [0, total_pts) — the state pcp_backproject_align_crop leaves behind
+ * when ITS overflow flag is set (true counts in offsets, rows beyond cap unwritten).  Such a cloud
+ * gets an all -1 / zero row; nothing is read or written out of bounds and no output row is left
+ * unwritten.  The offsets live on the device, so the host cannot know earlier: check the flag
+ * wherever the results are consumed.
  */
 size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo);
 int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
                     int64_t max_pts, int K, int dist_mode, int algo,
-                    int64_t* idx, float* out_xyz, void* ws, size_t ws_bytes, void* stream);
+                    int64_t* idx, float* out_xyz, int32_t* overflow,
+                    void* ws, size_t ws_bytes, void* stream);
 
 /*
  * Colour gather pc_rgb[idx], DP3:48.
- *   rgb (total,3) f32, offsets (B+1) i64, idx (B,K) i64, out (B,K,3) f32
+ *   rgb (total_pts,3) f32, offsets (B+1) i64, idx (B,K) i64, out (B,K,3) f32
  *   compat_neg_index 1: idx = -1 selects the cloud's LAST row (numpy negative
  *                       indexing, exactly what DP3:48 does with pytorch3d's padding)
  *                    0: idx = -1 yields zeros
+ * An index outside its cloud, or a row outside [0, total_pts) (a cloud that overflowed stage 1's
+ * capacity), yields zeros instead of an out-of-bounds read.
  */
-int pcp_gather_rgb(const float* rgb, const int64_t* offsets, const int64_t* idx, int B, int K,
-                   int compat_neg_index, float* out, void* stream);
+int pcp_gather_rgb(const float* rgb, const int64_t* offsets, int64_t total_pts, const int64_t* idx,
+                   int B, int K, int compat_neg_index, float* out, void* stream);
 
 /*
  * (K,6) rows exactly as chunking_data.py:134-144 stacks them for the zarr

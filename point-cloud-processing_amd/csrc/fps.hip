@@ -40,17 +40,28 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     return k;
 }
 
+// A cloud the launch cannot serve: CSR rows outside the caller's arrays (stage 1 reported a capacity overflow, or
+// the offsets are corrupt) or more points than the caller's `max_pts` bound let any launched shape take.
+__device__ __forceinline__ bool fps_cloud_out_of_bounds(long long base, long long M, long long total_pts, int m_cap)
+{
+    return base < 0 || M < 0 || base > total_pts || M > total_pts - base || M > (long long)m_cap;
+}
+
 // ---- brute force: one 1024-thread workgroup per cloud, min_d streamed through `md` ----------
 template <int MODE>
 __global__ void __launch_bounds__(1024)
 fps_brute(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
-          long long* __restrict__ idx, float* __restrict__ out_xyz, float* __restrict__ md)
+          long long* __restrict__ idx, float* __restrict__ out_xyz, float* __restrict__ md,
+          long long total_pts, int* __restrict__ overflow)
 {
     __shared__ unsigned long long part[2][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long base = offsets[b];
     const long long Mll = offsets[b + 1] - base;
-    const int M = (int)Mll;
+    // rows outside [0, total_pts) do not exist in xyz / the workspace: such a cloud gets an all -1 row and the flag
+    const bool bad = fps_cloud_out_of_bounds(base, Mll, total_pts, 0x7fffffff);
+    if (bad && tid == 0 && overflow) *overflow = 1;
+    const int M = bad ? 0 : (int)Mll;
     const int kn = K < M ? K : (M > 0 ? M : 0);
     long long* irow = idx + (size_t)b * K;
     float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
@@ -252,6 +263,7 @@ __device__ __forceinline__ float rl(float v, int lane)
 //             keys, one LDS partial per wave, ONE workgroup barrier, and every wave reduces the
 //             NW partials to the next sample (xyz included, so nothing global is on the
 //             critical path).
+#define PCP_FPS_RED 128          // floats of LDS scratch: bounding-box partials (6 per wave, <= 16 waves), scan scratch
 #define PCP_FPS_CELL_BITS 12
 #define PCP_FPS_NCELL (1 << PCP_FPS_CELL_BITS)
 #ifndef PCP_FPS_HILBERT
@@ -680,29 +692,40 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
 template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
-    return PCP_FPS_NCELL * 4 + 64 * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
+    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
 }
 
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
+                int* __restrict__ overflow)
 {
     // this launch serves the clouds with m_lo <= M <= m_hi; the others belong to a sibling launch
     constexpr int NW = T / 64, NBMAX = T * CPL, NCELL = PCP_FPS_NCELL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cellcnt = (int*)smem;                                           // [NCELL] histogram / cursors
-    float* red = (float*)(cellcnt + NCELL);                              // [64] bbox partials / scan scratch
-    unsigned long long* pkey = (unsigned long long*)(red + 64);          // [2][NW] wave partial keys
+    float* red = (float*)(cellcnt + NCELL);                              // [PCP_FPS_RED] bbox partials (6 per wave) / scan scratch (17)
+    static_assert(6 * NW <= PCP_FPS_RED && 17 <= PCP_FPS_RED, "red[] holds 6 floats per wave and the block scan's 17 ints");
+    unsigned long long* pkey = (unsigned long long*)(red + PCP_FPS_RED); // [2][NW] wave partial keys
     float4* pxyz = (float4*)(pkey + 2 * NW);                             // [2][NW] their xyz
     float4* bxyz = pxyz + 2 * NW;                                        // [NBMAX] xyz of every bucket's arg-max (written by its wave only)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long base = offsets[b];
-    const int M = (int)(offsets[b + 1] - base);
-    if (M < m_lo || M > m_hi) return;
+    const long long Mll = offsets[b + 1] - base;
+    // m_cap = the largest cloud any launch of this call takes.  A cloud beyond it, or one whose rows lie outside
+    // [0, total_pts), is nobody's: the launch that owns the top size range answers for it with an all -1 row and
+    // raises the caller's flag, so no row of idx / out_xyz is ever left unwritten.
+    const bool bad = fps_cloud_out_of_bounds(base, Mll, total_pts, m_cap);
+    if (bad) {
+        if (m_hi != m_cap) return;
+        if (tid == 0 && overflow) *overflow = 1;
+    }
+    const int M = bad ? 0 : (int)Mll;
+    if (!bad && (M < m_lo || M > m_hi)) return;
     const int kn = K < M ? K : (M > 0 ? M : 0);
     long long* irow = idx + (size_t)b * K;
     float* orow = out_xyz ? out_xyz + (size_t)b * K * 3 : nullptr;
@@ -975,9 +998,11 @@ template <int T, int CPL, int MODE, int BH = 1>
 __global__ void __launch_bounds__(T, 2048 / T) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
 fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
+                int* __restrict__ overflow)
 {
-    fps_bucket_body<T, CPL, false, MODE, BH>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
+    fps_bucket_body<T, CPL, false, MODE, BH>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
+                                             m_cap, overflow);
 }
 
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
@@ -985,9 +1010,11 @@ template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
 fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                float* __restrict__ md, int m_lo, int m_hi, int lazy_k)
+                float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
+                int* __restrict__ overflow)
 {
-    fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
+    fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts, m_cap,
+                                        overflow);
 }
 
 // ---- host entry points -------------------------------------------------------------------------
@@ -1011,20 +1038,36 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
 // buckets per lane, buckets of any multiple of 64 rows, beyond that.  The host only knows an upper bound on the
 // cloud sizes, so every shape the bound allows is launched and every workgroup keeps or drops its cloud by its
 // actual size (a dropped workgroup exits at once).
+struct FpsCall {                 // everything a launch needs besides its shape
+    const float* xyz;
+    const long long* offsets;
+    int B, K;
+    long long* idx;
+    float* out_xyz;
+    float4* pts4;
+    float* md;
+    long long total_pts;
+    int m_cap;                   // largest cloud any launch of this call takes (the top shape's m_hi)
+    int* overflow;
+    int lazy;
+    hipStream_t st;
+};
+
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
-static int launch_bucket_as(const float* xyz, const long long* offsets, int B, int K, long long* idx,
-                            float* out_xyz, float4* pts4, float* md, int m_lo, int m_hi, int lazy, hipStream_t st)
+static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
 {
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
-    void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int);
+    void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
+                 int, int*);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
     else kern = fps_bucket_wide<T, CPL, MODE, BH>;
     // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
     // (lazy: 0 = by batch size, 1 = always, -1 = never)
-    const int lazy_k = (!MULTI && CPL == 1 && lazy >= 0 && (lazy > 0 || B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;
-    if (lds > 48 * 1024)
+    const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;
+    if (lds > 48 * 1024)         // the only process-wide state the library touches: a per-kernel attribute, same value every time
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds, st, xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k);
+    hipLaunchKernelGGL(kern, dim3(c.B), dim3(T), lds, c.st, c.xyz, c.offsets, c.K, c.idx, c.out_xyz, c.pts4, c.md,
+                       m_lo, m_hi, lazy_k, c.total_pts, c.m_cap, c.overflow);
     return pcp_launch_status();
 }
 
@@ -1040,37 +1083,37 @@ static int launch_bucket_as(const float* xyz, const long long* offsets, int B, i
 #endif
 
 template <int MODE>
-static int launch_bucket(const float* xyz, const long long* offsets, int B, int64_t max_pts, int K,
-                         long long* idx, float* out_xyz, float4* pts4, float* md, int lazy, hipStream_t st)
+static int launch_bucket(FpsCall c, int64_t max_pts)
 {
-    if (PCP_FPS_SHAPE == 2)
-        return launch_bucket_as<512, 2, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
-                                                           PCP_FPS_WIDE_MAX, lazy, st);
-    int rc = launch_bucket_as<1024, 1, false, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md, 0,
-                                                          PCP_FPS_WIDE_MAX, lazy, st);
-    if (rc != PCP_OK || max_pts <= PCP_FPS_WIDE_MAX) return rc;
+    constexpr int W = PCP_FPS_WIDE_MAX;
+    constexpr int split_max = PCP_FPS_SPLIT4 ? 4 * W : 2 * W;
+    if (PCP_FPS_SHAPE == 2) {
+        c.m_cap = W;
+        return launch_bucket_as<512, 2, false, MODE>(c, 0, W);
+    }
+    // the top of the size range the launches below cover: a cloud beyond it (the caller understated max_pts) is
+    // answered with an all -1 row and the overflow flag by the last launch, never skipped
+    c.m_cap = max_pts <= W ? W : (max_pts <= 2 * W ? 2 * W : (max_pts <= split_max ? split_max : 0x7fffffff));
+    int rc = launch_bucket_as<1024, 1, false, MODE>(c, 0, W);
+    if (rc != PCP_OK || max_pts <= W) return rc;
     // up to 131,072 / 262,144 points: the same shape with buckets of two / four 64-row parts, streamed side by side
-    rc = launch_bucket_as<1024, 1, false, MODE, 2>(xyz, offsets, B, K, idx, out_xyz, pts4, md, PCP_FPS_WIDE_MAX + 1,
-                                                   2 * PCP_FPS_WIDE_MAX, lazy, st);
-    if (rc != PCP_OK || max_pts <= 2 * PCP_FPS_WIDE_MAX) return rc;
-    constexpr int split_max = PCP_FPS_SPLIT4 ? 4 * PCP_FPS_WIDE_MAX : 2 * PCP_FPS_WIDE_MAX;
+    rc = launch_bucket_as<1024, 1, false, MODE, 2>(c, W + 1, 2 * W);
+    if (rc != PCP_OK || max_pts <= 2 * W) return rc;
     if (PCP_FPS_SPLIT4) {
-        rc = launch_bucket_as<1024, 1, false, MODE, 4>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                       2 * PCP_FPS_WIDE_MAX + 1, 4 * PCP_FPS_WIDE_MAX, lazy, st);
-        if (rc != PCP_OK || max_pts <= 4 * PCP_FPS_WIDE_MAX) return rc;
+        rc = launch_bucket_as<1024, 1, false, MODE, 4>(c, 2 * W + 1, 4 * W);
+        if (rc != PCP_OK || max_pts <= 4 * W) return rc;
     }
     // larger clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
     // twice the waves streaming and half the rows per bucket; bigger batches keep two 512-thread workgroups per CU
-    if (B <= PCP_FPS_DEEP_1024_MAX_B)
-        return launch_bucket_as<1024, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                            split_max + 1, 0x7fffffff, lazy, st);
-    return launch_bucket_as<512, 2, true, MODE>(xyz, offsets, B, K, idx, out_xyz, pts4, md,
-                                                       split_max + 1, 0x7fffffff, lazy, st);
+    if (c.B <= PCP_FPS_DEEP_1024_MAX_B)
+        return launch_bucket_as<1024, 2, true, MODE>(c, split_max + 1, 0x7fffffff);
+    return launch_bucket_as<512, 2, true, MODE>(c, split_max + 1, 0x7fffffff);
 }
 
-extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
-                               int64_t max_pts, int K, int dist_mode, int algo, int64_t* idx,
-                               float* out_xyz, void* ws, size_t ws_bytes, void* stream)
+// shared by pcp_fps_batched and its no-allocation twin: argument checks, workspace carve-up, launches
+static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
+                            int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
+                            void* ws, size_t ws_bytes, hipStream_t st)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
         algo < 0 || algo > 4)
@@ -1079,19 +1122,30 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_fps_workspace_bytes(B, total_pts, max_pts, K, algo))
         return PCP_ERR_WORKSPACE;
+    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
     if (B == 0 || K == 0) return PCP_OK;
-    hipStream_t st = (hipStream_t)stream;
-    float4* pts4 = (float4*)ws;
-    float* md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
-    const long long* off = (const long long*)offsets;
-    if (fps_pick_algo(algo, max_pts) == 2) {
-        const int lazy = algo == 3 ? 1 : (algo == 4 ? -1 : 0);
-        return dist_mode == 0 ? launch_bucket<0>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, lazy, st)
-                              : launch_bucket<1>(xyz, off, B, max_pts, K, (long long*)idx, out_xyz, pts4, md, lazy, st);
-    }
+    FpsCall c;
+    c.xyz = xyz; c.offsets = (const long long*)offsets; c.B = B; c.K = K; c.idx = (long long*)idx; c.out_xyz = out_xyz;
+    c.pts4 = (float4*)ws;
+    c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
+    c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
+    c.lazy = algo == 3 ? 1 : (algo == 4 ? -1 : 0);
+    c.st = st;
+    if (fps_pick_algo(algo, max_pts) == 2)
+        return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);
     if (dist_mode == 0)
-        hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
+        hipLaunchKernelGGL(fps_brute<0>, dim3(B), dim3(1024), 0, st, xyz, c.offsets, K, c.idx, out_xyz, c.md,
+                           c.total_pts, overflow);
     else
-        hipLaunchKernelGGL(fps_brute<1>, dim3(B), dim3(1024), 0, st, xyz, off, K, (long long*)idx, out_xyz, md);
+        hipLaunchKernelGGL(fps_brute<1>, dim3(B), dim3(1024), 0, st, xyz, c.offsets, K, c.idx, out_xyz, c.md,
+                           c.total_pts, overflow);
     return pcp_launch_status();
+}
+
+extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
+                               int64_t max_pts, int K, int dist_mode, int algo, int64_t* idx,
+                               float* out_xyz, int32_t* overflow, void* ws, size_t ws_bytes, void* stream)
+{
+    return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
+                            ws_bytes, (hipStream_t)stream);
 }

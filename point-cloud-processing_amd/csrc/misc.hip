@@ -4,7 +4,7 @@
 #include "pcp_internal.h"
 
 __global__ void __launch_bounds__(256)
-gather_rgb_k(const float* __restrict__ rgb, const long long* __restrict__ offsets,
+gather_rgb_k(const float* __restrict__ rgb, const long long* __restrict__ offsets, long long total_pts,
              const long long* __restrict__ idx, int K, int compat_neg, float* __restrict__ out)
 {
     const int b = blockIdx.y;
@@ -17,6 +17,9 @@ gather_rgb_k(const float* __restrict__ rgb, const long long* __restrict__ offset
         if (compat_neg && M > 0 && i + M >= 0) i += M;        // numpy negative indexing, DP3:48
         else { o[0] = o[1] = o[2] = 0.f; return; }
     }
+    // a row outside the cloud or outside the caller's array (a cloud stage 1 could not store: capacity overflow)
+    // reads nothing: zeros.  numpy would raise IndexError here; the flag of the producing call is the error report.
+    if (i >= M || base < 0 || base + i >= total_pts) { o[0] = o[1] = o[2] = 0.f; return; }
     const float* s = rgb + 3 * (base + i);
     o[0] = s[0]; o[1] = s[1]; o[2] = s[2];
 }
@@ -56,14 +59,14 @@ extern "C" int pcp_depth_mm_to_m(const uint16_t* depth_mm, int64_t n, float* dep
     return pcp_launch_status();
 }
 
-extern "C" int pcp_gather_rgb(const float* rgb, const int64_t* offsets, const int64_t* idx, int B,
-                              int K, int compat_neg_index, float* out, void* stream)
+extern "C" int pcp_gather_rgb(const float* rgb, const int64_t* offsets, int64_t total_pts, const int64_t* idx,
+                              int B, int K, int compat_neg_index, float* out, void* stream)
 {
-    if (B < 0 || K < 0) return PCP_ERR_INVALID_ARG;
+    if (B < 0 || K < 0 || total_pts < 0) return PCP_ERR_INVALID_ARG;
     if (B == 0 || K == 0) return PCP_OK;
-    if (!rgb || !offsets || !idx || !out) return PCP_ERR_INVALID_ARG;
+    if ((total_pts > 0 && !rgb) || !offsets || !idx || !out) return PCP_ERR_INVALID_ARG;
     hipLaunchKernelGGL(gather_rgb_k, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, rgb,
-                       (const long long*)offsets, (const long long*)idx, K, compat_neg_index, out);
+                       (const long long*)offsets, (long long)total_pts, (const long long*)idx, K, compat_neg_index, out);
     return pcp_launch_status();
 }
 
@@ -112,7 +115,7 @@ extern "C" const char* pcp_strerror(int status)
     }
 }
 
-extern "C" const char* pcp_version(void) { return "pcp-hip 0.1 gfx950"; }
+extern "C" const char* pcp_version(void) { return "pcp-hip 0.2 gfx950"; }
 
 extern "C" int pcp_device_count(void)
 {

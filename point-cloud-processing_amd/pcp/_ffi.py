@@ -79,9 +79,9 @@ def load_library():
     L.pcp_crop_compact_batched.argtypes = [vp, vp, vp, i32, i64, d3, d3, vp, vp, vp, vp, i64, vp, sz, vp]
     L.pcp_crop_compact_batched.restype = i32
     L.pcp_fps_workspace_bytes.argtypes = [i32, i64, i64, i32, i32]; L.pcp_fps_workspace_bytes.restype = sz
-    L.pcp_fps_batched.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, sz, vp]
+    L.pcp_fps_batched.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, vp, sz, vp]
     L.pcp_fps_batched.restype = i32
-    L.pcp_gather_rgb.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]; L.pcp_gather_rgb.restype = i32
+    L.pcp_gather_rgb.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, vp]; L.pcp_gather_rgb.restype = i32
     L.pcp_pack_dp3.argtypes = [vp, vp, i32, i32, vp, vp]; L.pcp_pack_dp3.restype = i32
     f64 = C.c_double
     L.pcp_voxel_workspace_bytes.argtypes = [i32, i64]; L.pcp_voxel_workspace_bytes.restype = sz

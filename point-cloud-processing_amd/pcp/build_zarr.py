@@ -64,8 +64,18 @@ def _process_traj(data_root, traj, source, K, frame_skip, intr, ext, runner_box)
         if runner is None or (runner.H, runner.W) != d0.shape:
             p = _ffi.make_params(intr_t["depth"], intr_t["color"], T=xpc.T_DEPTH_TO_COLOR, ext=ext, apply_crop=True)
             runner = runner_box["runner"] = EpisodeRunner(d0.shape[0], d0.shape[1], K, p, device=runner_box.get("device", "cuda"))
-        all_rows, _, ids = runner.run_tree(extracted)
-        rows = [all_rows[i] for i in s_idx if i < len(all_rows)]
+        all_rows, counts, ids = runner.run_tree(extracted)
+        # The reference's route writes one filtered PLY per frame that has both input files (XPC:100-101) until a
+        # frame crops to zero points: pytorch3d then raises inside DP3:47, the bag's child process dies
+        # (S2:15-18,45) and the later frames never get a file.  CHK:123-125 then pairs states with the sorted
+        # file list BY POSITION, and CHK:127-132 skips the trajectory when the counts differ.  Same here: the
+        # rows that "exist" are those before the first empty crop, paired by position.
+        empty = np.nonzero(np.asarray(counts) == 0)[0]
+        n_ok = int(empty[0]) if len(empty) else len(all_rows)
+        if len(empty):
+            print(f"Error: frame {ids[n_ok]} of {traj} has no point inside the workspace "
+                  f"(the reference's filter step fails there, S2:15-18)")
+        rows = [all_rows[i] for i in s_idx if i < n_ok]
     if len(rows) != state.shape[0]:
         print(f"Warning: {traj} has {state.shape[0]} states but {len(rows)} point clouds. Skipping.")   # CHK:127-132
         return None
@@ -97,7 +107,15 @@ def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, comp
         trajs.append(traj)
     from pcp import shard
     mine = shard.assign_episodes([_count_states(os.path.join(data_root, t, "extracted_data", t)) for t in trajs], world)[rank]
-    runner_box = {"device": f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"}
+    runner_box = {}
+    if source == "gpu":
+        import torch
+        ndev = torch.cuda.device_count()
+        if ndev == 0:
+            raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
+        local_dev = int(os.environ.get("LOCAL_RANK", "0")) % ndev       # rehearsals with more ranks than GPUs share devices
+        torch.cuda.set_device(local_dev)                                # libpcp launches on the current device
+        runner_box["device"] = f"cuda:{local_dev}"
     local = {i: _process_traj(data_root, trajs[i], source, K, frame_skip, intr, ext, runner_box) for i in mine}
     results = shard.gather_episodes(local, len(trajs))
     pcs, actions, states, ends, total = [], [], [], [], 0

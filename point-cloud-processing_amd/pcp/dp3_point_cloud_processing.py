@@ -15,7 +15,9 @@ from pcp import ops, ply  # noqa: E402
 
 WORK_SPACE = ((-0.05, 0.4), (-0.12, 0.35), (-0.008, 0.6))      # DP3:29-33
 NUM_POINTS = 2500                                              # DP3:47
-DIST_MODE = int(os.environ.get("PCP_DIST_MODE", "0"))          # 0 un-fused (default), 1 fused (CUDA pytorch3d)
+
+dist_mode_for = ops.dist_mode_for
+REFERENCE_USE_CUDA = True                                      # DP3:47 hard-codes use_cuda=True
 
 
 def _device():
@@ -26,18 +28,20 @@ def _device():
 
 def farthest_point_sampling(points, num_points=2500, use_cuda=False):
     """DP3:7-21.  points (M,3) ndarray → (sampled (num_points,3) float32, idx (num_points,) int64).
-    `use_cuda` is accepted for signature compatibility; the sampling always runs on the GPU."""
+    The sampling always runs on the MI355X; `use_cuda` selects the distance arithmetic of the pytorch3d build the
+    reference would have used (True: CUDA kernel, fused; False: CPU build, un-fused) — see dist_mode_for()."""
     pts = torch.from_numpy(np.ascontiguousarray(points)).float().to(_device())        # DP3:10-12
     m = pts.shape[0]
     if m == 0:
         raise ValueError("farthest_point_sampling: empty point cloud")              # reference dies in pytorch3d
     off = torch.tensor([0, m], dtype=torch.int64, device=pts.device)
-    xyz, idx = ops.fps_batched(pts.contiguous(), off, int(num_points), dist_mode=DIST_MODE, max_pts=m)
+    xyz, idx = ops.fps_batched(pts.contiguous(), off, int(num_points), dist_mode=dist_mode_for(use_cuda), max_pts=m)
     return xyz[0].cpu().numpy(), idx[0].cpu().numpy()                                 # DP3:18-19
 
 
-def process_point_cloud(pc_xyz, pc_rgb, num_points=NUM_POINTS, verbose=True):
-    """DP3:23-52: crop (six strict f64 compares) → FPS → pc_rgb[idx] (negative index = last row)."""
+def process_point_cloud(pc_xyz, pc_rgb, num_points=NUM_POINTS, verbose=True, use_cuda=REFERENCE_USE_CUDA):
+    """DP3:23-52: crop (six strict f64 compares) → FPS → pc_rgb[idx] (negative index = last row).
+    The reference samples with use_cuda=True (DP3:47), hence the fused distance mode by default."""
     dev = _device()
     xyz = torch.from_numpy(np.ascontiguousarray(pc_xyz, dtype=np.float64)).to(dev)
     rgb = torch.from_numpy(np.ascontiguousarray(pc_rgb, dtype=np.float64)).to(dev)
@@ -49,7 +53,7 @@ def process_point_cloud(pc_xyz, pc_rgb, num_points=NUM_POINTS, verbose=True):
     if m == 0:
         raise ValueError("process_point_cloud: no point inside the workspace")
     off = torch.tensor([0, m], dtype=torch.int64, device=dev)
-    fxyz, idx = ops.fps_batched(x32.contiguous(), off, int(num_points), dist_mode=DIST_MODE, max_pts=m)
+    fxyz, idx = ops.fps_batched(x32.contiguous(), off, int(num_points), dist_mode=dist_mode_for(use_cuda), max_pts=m)
     sel = idx[0]
     sel = torch.where(sel < 0, sel + m, sel)                                           # DP3:48 numpy negative index
     pc_rgb_fps = c64.index_select(0, sel).cpu().numpy()
@@ -66,7 +70,8 @@ def save_ply(path, xyz, rgb):
 BATCH = int(os.environ.get("PCP_STAGE2_BATCH", "64"))          # clouds per launch sequence in process()
 
 
-def process_point_clouds_batched(clouds, num_points=NUM_POINTS, voxel_size=None, sor=None):
+def process_point_clouds_batched(clouds, num_points=NUM_POINTS, voxel_size=None, sor=None,
+                                 use_cuda=REFERENCE_USE_CUDA):
     """process_point_cloud (DP3:23-52) for a list of (pc_xyz, pc_rgb) pairs in ONE launch sequence: batched
     crop, batched FPS, one colour gather.  Returns [(xyz (K,3) f32, rgb (K,3) f64, cropped_count)]; a cloud
     with no point inside the workspace yields None (the serial loop raises for it, see process()).
@@ -101,10 +106,11 @@ def process_point_clouds_batched(clouds, num_points=NUM_POINTS, voxel_size=None,
             return [None] * len(clouds)
         x32, c64 = x64.float().contiguous(), c32.double()
     counts = np.diff(out_off.cpu().numpy())
-    fxyz, idx = ops.fps_batched(x32[:total].contiguous(), out_off, int(num_points), dist_mode=DIST_MODE,
-                                max_pts=int(counts.max()))
+    fxyz, idx = ops.fps_batched(x32[:total].contiguous(), out_off, int(num_points),
+                                dist_mode=dist_mode_for(use_cuda), max_pts=int(counts.max()))
     m = torch.from_numpy(counts).to(dev).unsqueeze(1)
-    sel = torch.where(idx < 0, idx + m, idx).clamp_(min=0) + out_off[:-1].unsqueeze(1)     # DP3:48 numpy negative index
+    sel = torch.where(idx < 0, idx + m, idx) + out_off[:-1].unsqueeze(1)                   # DP3:48 numpy negative index
+    sel = torch.where(m > 0, sel, torch.zeros_like(sel))       # an empty crop has no row to gather (reported as None below)
     col = c64[:max(total, 1)].index_select(0, sel.reshape(-1)).reshape(len(clouds), int(num_points), 3).cpu().numpy()
     pts = fxyz.cpu().numpy()
     return [None if counts[b] == 0 else (pts[b], col[b], int(counts[b])) for b in range(len(clouds))]

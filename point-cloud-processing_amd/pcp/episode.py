@@ -12,7 +12,7 @@ from . import _ffi, ops
 
 
 class EpisodeRunner:
-    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=0, Hc=None, Wc=None, depth_mm=False,
+    def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=None, Hc=None, Wc=None, depth_mm=False,
                  stage_threads=8, upload_piece=25):
         if not torch.cuda.is_available():
             raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
@@ -20,7 +20,12 @@ class EpisodeRunner:
         self.depth_mm = bool(depth_mm)          # chunks carry raw uint16 millimetres: half the upload, /1000 on the device
         self.Hc, self.Wc = Hc or H, Wc or W
         self.dev = torch.device(device)
-        self.pipe = ops.FramePipeline(self.chunk, H, W, K, params, self.dev, dist_mode=dist_mode)
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
+        if dist_mode is None:                   # the loop this replaces samples with use_cuda=True (DP3:47)
+            dist_mode = ops.dist_mode_for(True)
+        self.dist_mode = int(dist_mode)
+        self.pipe = ops.FramePipeline(self.chunk, H, W, K, params, self.dev, dist_mode=self.dist_mode)
         self.copy_stream = torch.cuda.Stream(device=self.dev)
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         ddt = torch.uint16 if self.depth_mm else torch.float32
@@ -33,6 +38,7 @@ class EpisodeRunner:
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.h_rows = mk((self.chunk, K, 6), torch.float32)
         self.h_off = mk((self.chunk + 1,), torch.int64)
+        self.h_flags = mk((2,), torch.int32)                 # stage-1 capacity / FPS bounds flags of the chunk
         self.done = torch.cuda.Event()
         self.stage_threads = max(1, int(stage_threads))
         self.upload_piece = int(upload_piece)                # frames per staging/DMA piece
@@ -91,6 +97,10 @@ class EpisodeRunner:
         Returns (T,K,6) float32 DP3 rows and the (T,) cropped point counts.
         Order per chunk: enqueue its kernels + D2H, THEN decode/stage/upload the next chunk on the host
         and the copy stream while the GPU works, then collect the rows."""
+        with torch.cuda.device(self.dev):                    # events, streams and kernels all belong to self.dev
+            return self._run_chunks(chunks)
+
+    def _run_chunks(self, chunks):
         rows, counts = [], []
         main = torch.cuda.current_stream(self.dev)
         for s in range(2):
@@ -109,12 +119,17 @@ class EpisodeRunner:
             self.consumed[cur_slot].record(main)
             self.h_rows.copy_(packed, non_blocking=True)
             self.h_off.copy_(off, non_blocking=True)
+            self.h_flags[0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
+            self.h_flags[1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
             self.done.record(main)
             nxt = next(it, None)
             if nxt is not None:
                 slot ^= 1
                 self._upload(slot, *nxt)
             self.done.synchronize()
+            if int(self.h_flags[0]) or int(self.h_flags[1]):
+                raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if int(self.h_flags[0]) else
+                                    "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
             rows.append(self.h_rows[:cur_n].numpy().copy())
             counts.append(np.diff(self.h_off.numpy())[:cur_n])
         if not rows:

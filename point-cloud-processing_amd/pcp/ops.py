@@ -8,6 +8,19 @@ from . import _ffi
 from ._ffi import Params, check, load_library
 
 
+def dist_mode_for(use_cuda):
+    """FPS distance precision that follows the reference's device choice (DP3:11-16): `use_cuda=True` runs
+    pytorch3d's CUDA kernel, whose `dist2 += diff*diff` nvcc contracts into FMAs (dist_mode 1); `use_cuda=False`
+    runs the x86 CPU build, every operation rounded (dist_mode 0).  PCP_DIST_MODE=0|1 overrides both."""
+    import os
+    env = os.environ.get("PCP_DIST_MODE")
+    if env is not None and env != "":
+        if env not in ("0", "1"):
+            raise ValueError("PCP_DIST_MODE must be 0 or 1")
+        return int(env)
+    return 1 if use_cuda else 0
+
+
 def _require_cuda(*tensors):
     if not torch.cuda.is_available():
         raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
@@ -28,8 +41,17 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """torch's current HIP stream ON `device` (default: the current device) as a void*."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _call(device, fn, *args):
+    """Run one C-ABI entry point with `device` current and torch's current stream of THAT device appended as the
+    trailing `stream` argument.  libpcp launches on the current HIP device (include/pcp.h), so on a multi-GPU host a
+    tensor on cuda:1 must not be processed while cuda:0 is current."""
+    with torch.cuda.device(device):
+        check(fn(*args, _stream(device)))
 
 
 def _workspace(nbytes, device):
@@ -51,9 +73,9 @@ def backproject_dense(depth, rgb, params, want=("pts_cam", "colors", "proj_mask"
                 pts_base=((B, n, 3), torch.float64), crop_mask=((B, n), torch.uint8))
     out = {k: torch.empty(spec[k][0], dtype=spec[k][1], device=dev) for k in want}
     g = lambda k: _ptr(out.get(k))
-    check(load_library().pcp_backproject_dense(
-        _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("pts_cam"), g("colors"),
-        g("proj_mask"), g("valid"), g("pts_base"), g("crop_mask"), _stream()))
+    _call(dev, load_library().pcp_backproject_dense,
+          _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("pts_cam"), g("colors"),
+          g("proj_mask"), g("valid"), g("pts_base"), g("crop_mask"))
     return out
 
 
@@ -65,8 +87,8 @@ def align_colors(pts_cam, rgb, color_intr, T_depth_to_color):
     p = _ffi.make_params(color_intr, color_intr, T=T_depth_to_color, apply_crop=False)
     colors = torch.empty((n, 3), dtype=torch.float32, device=pts_cam.device)
     mask = torch.empty(n, dtype=torch.uint8, device=pts_cam.device)
-    check(load_library().pcp_align_colors(_ptr(pts_cam), n, _ptr(rgb), rgb.shape[0], rgb.shape[1],
-                                          C.byref(p), _ptr(colors), _ptr(mask), _stream()))
+    _call(pts_cam.device, load_library().pcp_align_colors, _ptr(pts_cam), n, _ptr(rgb), rgb.shape[0], rgb.shape[1],
+          C.byref(p), _ptr(colors), _ptr(mask))
     return colors, mask
 
 
@@ -76,7 +98,7 @@ def depth_mm_to_m(depth_mm, out=None):
     _chk(depth_mm, torch.uint16, "depth_mm")
     if out is None:
         out = torch.empty(depth_mm.shape, dtype=torch.float32, device=depth_mm.device)
-    check(load_library().pcp_depth_mm_to_m(_ptr(depth_mm), depth_mm.numel(), _ptr(out), _stream()))
+    _call(depth_mm.device, load_library().pcp_depth_mm_to_m, _ptr(depth_mm), depth_mm.numel(), _ptr(out))
     return out
 
 
@@ -86,6 +108,9 @@ class Stage1:
     def __init__(self, B, H, W, device, cap=None, want=("xyz32", "rgb32")):
         L = load_library()
         self.B, self.H, self.W = B, H, W
+        self.device = device = torch.device(device)
+        if device.index is None:
+            self.device = device = torch.device("cuda", torch.cuda.current_device())
         self.cap = int(cap if cap is not None else B * H * W)
         self.ws_bytes = L.pcp_backproject_workspace_bytes(B, H, W)
         self.ws = _workspace(self.ws_bytes, device)
@@ -107,10 +132,10 @@ class Stage1:
             raise ValueError("depth shape does not match the Stage1 plan")
         Hc, Wc = rgb.shape[1], rgb.shape[2]
         g = lambda k: _ptr(self.out.get(k))
-        check(load_library().pcp_backproject_align_crop(
-            _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("xyz_cam64"), g("xyz64"),
-            g("xyz32"), g("rgb32"), g("pix"), _ptr(self.offsets), self.cap, _ptr(self.overflow),
-            _ptr(self.ws), self.ws_bytes, _stream()))
+        _call(self.device, load_library().pcp_backproject_align_crop,
+              _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("xyz_cam64"), g("xyz64"),
+              g("xyz32"), g("rgb32"), g("pix"), _ptr(self.offsets), self.cap, _ptr(self.overflow),
+              _ptr(self.ws), self.ws_bytes)
         return self.out, self.offsets
 
 
@@ -131,10 +156,10 @@ class Stage1MultiCam(Stage1):
         Hc, Wc = rgb.shape[2], rgb.shape[3]
         arr = (Params * Cn)(*cams)
         g = lambda k: _ptr(self.out.get(k))
-        check(load_library().pcp_backproject_align_crop_multicam(
-            _ptr(depth), _ptr(rgb), F, Cn, H, W, Hc, Wc, arr, g("xyz_cam64"), g("xyz64"), g("xyz32"),
-            g("rgb32"), g("pix"), _ptr(self.offsets), _ptr(self.fused_offsets), self.cap, _ptr(self.overflow),
-            _ptr(self.ws), self.ws_bytes, _stream()))
+        _call(self.device, load_library().pcp_backproject_align_crop_multicam,
+              _ptr(depth), _ptr(rgb), F, Cn, H, W, Hc, Wc, arr, g("xyz_cam64"), g("xyz64"), g("xyz32"),
+              g("rgb32"), g("pix"), _ptr(self.offsets), _ptr(self.fused_offsets), self.cap, _ptr(self.overflow),
+              _ptr(self.ws), self.ws_bytes)
         return self.out, self.fused_offsets, self.offsets
 
 
@@ -143,7 +168,7 @@ def crop_mask(xyz, lo, hi):
     _chk(xyz, torch.float64, "xyz")
     m = torch.empty(xyz.shape[0], dtype=torch.uint8, device=xyz.device)
     lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
-    check(load_library().pcp_crop_mask(_ptr(xyz), xyz.shape[0], lo3, hi3, _ptr(m), _stream()))
+    _call(xyz.device, load_library().pcp_crop_mask, _ptr(xyz), xyz.shape[0], lo3, hi3, _ptr(m))
     return m
 
 
@@ -162,8 +187,8 @@ def crop_compact(xyz, rgb, lo, hi, want_xyz64=True, want_xyz32=True):
     orgb = torch.empty((M1, 3), dtype=torch.float64, device=dev) if rgb is not None else None
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
-    check(L.pcp_crop_compact(_ptr(xyz), _ptr(rgb), M1, lo3, hi3, _ptr(o64), _ptr(o32), _ptr(orgb),
-                             M1, _ptr(count), _ptr(ws), nb, _stream()))
+    _call(dev, L.pcp_crop_compact, _ptr(xyz), _ptr(rgb), M1, lo3, hi3, _ptr(o64), _ptr(o32), _ptr(orgb),
+          M1, _ptr(count), _ptr(ws), nb)
     m = int(count.item())
     cut = lambda t: None if t is None else t[:m]
     return cut(o64), cut(o32), cut(orgb), m
@@ -185,8 +210,8 @@ def crop_compact_batched(xyz, rgb, offsets, lo, hi, want_xyz64=False):
     orgb = torch.empty((n, 3), dtype=torch.float64, device=dev) if rgb is not None else None
     out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     lo3, hi3 = (C.c_double * 3)(*lo), (C.c_double * 3)(*hi)
-    check(L.pcp_crop_compact_batched(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, lo3, hi3, _ptr(o64), _ptr(o32),
-                                     _ptr(orgb), _ptr(out_off), n, _ptr(ws), nb, _stream()))
+    _call(dev, L.pcp_crop_compact_batched, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, lo3, hi3, _ptr(o64), _ptr(o32),
+          _ptr(orgb), _ptr(out_off), n, _ptr(ws), nb)
     return o64, o32, orgb, out_off
 
 
@@ -197,10 +222,14 @@ class Fps:
         L = load_library()
         self.B, self.K, self.total_cap, self.max_pts = B, K, int(total_cap), int(max_pts)
         self.dist_mode, self.algo = dist_mode, algo
+        self.device = device = torch.device(device)
+        if device.index is None:
+            self.device = device = torch.device("cuda", torch.cuda.current_device())
         self.ws_bytes = L.pcp_fps_workspace_bytes(B, self.total_cap, self.max_pts, K, algo)
         self.ws = _workspace(self.ws_bytes, device)
         self.idx = torch.empty((B, K), dtype=torch.int64, device=device)
         self.xyz = torch.empty((B, K, 3), dtype=torch.float32, device=device)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)   # set by the kernels, see pcp.h
 
     def run(self, xyz, offsets):
         _require_cuda(xyz, offsets)
@@ -209,10 +238,14 @@ class Fps:
             raise ValueError("offsets must have B+1 entries")
         if xyz.shape[0] > self.total_cap:
             raise ValueError("more points than the Fps plan was sized for")
-        check(load_library().pcp_fps_batched(
-            _ptr(xyz), _ptr(offsets), self.B, xyz.shape[0], self.max_pts, self.K, self.dist_mode,
-            self.algo, _ptr(self.idx), _ptr(self.xyz), _ptr(self.ws), self.ws_bytes, _stream()))
+        self.enqueue(xyz, offsets, xyz.shape[0])
         return self.xyz, self.idx
+
+    def enqueue(self, xyz, offsets, total_pts):
+        """The bare C-ABI call (no checks): rows [0, total_pts) of xyz exist."""
+        _call(self.device, load_library().pcp_fps_batched,
+              _ptr(xyz), _ptr(offsets), self.B, int(total_pts), self.max_pts, self.K, self.dist_mode,
+              self.algo, _ptr(self.idx), _ptr(self.xyz), _ptr(self.overflow), _ptr(self.ws), self.ws_bytes)
 
 
 def fps_batched(xyz, offsets, K, dist_mode=0, algo=0, max_pts=None):
@@ -228,8 +261,8 @@ def gather_rgb(rgb, offsets, idx, compat_neg_index=True):
     _chk(rgb, torch.float32, "rgb"); _chk(offsets, torch.int64, "offsets"); _chk(idx, torch.int64, "idx")
     B, K = idx.shape
     out = torch.empty((B, K, 3), dtype=torch.float32, device=rgb.device)
-    check(load_library().pcp_gather_rgb(_ptr(rgb), _ptr(offsets), _ptr(idx), B, K,
-                                        1 if compat_neg_index else 0, _ptr(out), _stream()))
+    _call(rgb.device, load_library().pcp_gather_rgb, _ptr(rgb), _ptr(offsets), rgb.shape[0], _ptr(idx), B, K,
+          1 if compat_neg_index else 0, _ptr(out))
     return out
 
 
@@ -238,7 +271,7 @@ def pack_dp3(xyz, rgb):
     _chk(xyz, torch.float32, "xyz"); _chk(rgb, torch.float32, "rgb")
     B, K = xyz.shape[0], xyz.shape[1]
     out = torch.empty((B, K, 6), dtype=torch.float32, device=xyz.device)
-    check(load_library().pcp_pack_dp3(_ptr(xyz), _ptr(rgb), B, K, _ptr(out), _stream()))
+    _call(xyz.device, load_library().pcp_pack_dp3, _ptr(xyz), _ptr(rgb), B, K, _ptr(out))
     return out
 
 
@@ -269,9 +302,9 @@ def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None):
     out["count"] = torch.empty((n,), dtype=torch.int32, device=dev)
     out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(L.pcp_voxel_downsample(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, float(voxel_size), _ptr(out["xyz64"]),
-                                 _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["count"]), _ptr(out_off), n,
-                                 _ptr(ovf), _ptr(ws), nb, _stream()))
+    _call(dev, L.pcp_voxel_downsample, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, float(voxel_size), _ptr(out["xyz64"]),
+          _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["count"]), _ptr(out_off), n,
+          _ptr(ovf), _ptr(ws), nb)
     out["overflow"] = ovf
     return out, out_off
 
@@ -311,10 +344,10 @@ def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.
     out["avg"] = torch.zeros((n,), dtype=torch.float64, device=dev)
     out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    check(L.pcp_statistical_outlier_removal(_ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, int(nb_neighbors),
-                                            float(std_ratio), float(cell_size), _ptr(out["xyz64"]),
-                                            _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["index"]),
-                                            _ptr(out_off), _ptr(out["avg"]), n, _ptr(ovf), _ptr(ws), nb, _stream()))
+    _call(dev, L.pcp_statistical_outlier_removal, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, int(nb_neighbors),
+          float(std_ratio), float(cell_size), _ptr(out["xyz64"]),
+          _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["index"]),
+          _ptr(out_off), _ptr(out["avg"]), n, _ptr(ovf), _ptr(ws), nb)
     out["overflow"] = ovf
     return out, out_off
 
@@ -332,11 +365,17 @@ class FramePipeline:
 
     def run(self, depth, rgb):
         out, offsets = self.stage1.run(depth, rgb, self.params)
-        L = load_library()
         f = self.fps
-        check(L.pcp_fps_batched(_ptr(out["xyz32"]), _ptr(offsets), f.B, self.stage1.cap, f.max_pts, f.K,
-                                f.dist_mode, f.algo, _ptr(f.idx), _ptr(f.xyz), _ptr(f.ws), f.ws_bytes,
-                                _stream()))
-        check(L.pcp_gather_rgb(_ptr(out["rgb32"]), _ptr(offsets), _ptr(f.idx), f.B, f.K, 1,
-                               _ptr(self.rgb_out), _stream()))
+        # total_pts = the rows stage 1 could store: if its capacity overflowed, offsets hold the TRUE counts and the FPS
+        # and gather kernels drop every cloud that reaches past `cap` (all -1 / zero rows, f.overflow set)
+        f.enqueue(out["xyz32"], offsets, self.stage1.cap)
+        _call(f.device, load_library().pcp_gather_rgb, _ptr(out["rgb32"]), _ptr(offsets), self.stage1.cap,
+              _ptr(f.idx), f.B, f.K, 1, _ptr(self.rgb_out))
         return f.xyz, self.rgb_out, f.idx, offsets
+
+    def check(self):
+        """Synchronising: raise if the last run() lost rows (stage-1 capacity) or skipped a cloud (FPS bounds)."""
+        flags = torch.stack([self.stage1.overflow[0], self.fps.overflow[0]]).cpu().tolist()
+        if flags[0] or flags[1]:
+            raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if flags[0] else
+                                "a cloud exceeded max_pts / total_pts in pcp_fps_batched")

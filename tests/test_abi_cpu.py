@@ -48,9 +48,9 @@ def test_argument_validation_without_device():
     p = _ffi.default_params()
     # zero intrinsics / null depth are rejected before any HIP call
     assert L.pcp_backproject_dense(None, None, 1, 4, 4, 4, 4, C.byref(p), *([None] * 7)) == -1
-    assert L.pcp_fps_batched(None, None, 1, 0, 0, 4, 0, 0, None, None, None, 0, None) == -1
-    assert L.pcp_fps_batched(None, None, 1, 0, 0, 4, 7, 0, None, None, None, 0, None) == -1
-    assert L.pcp_gather_rgb(None, None, None, -1, 4, 1, None, None) == -1
+    assert L.pcp_fps_batched(None, None, 1, 0, 0, 4, 0, 0, None, None, None, None, 0, None) == -1
+    assert L.pcp_fps_batched(None, None, 1, 0, 0, 4, 7, 0, None, None, None, None, 0, None) == -1
+    assert L.pcp_gather_rgb(None, None, 0, None, -1, 4, 1, None, None) == -1
     assert L.pcp_backproject_workspace_bytes(300, 480, 640) >= 300 * 300 * 16 * 8
     assert L.pcp_fps_workspace_bytes(1, 1000, 1000, 16, 0) >= 4000
     assert L.pcp_crop_workspace_bytes(0) >= 256

@@ -11,7 +11,7 @@ import pytest
 
 from oracle import cbind, numpy_ref as R
 from pcp import ply
-from helpers import load_npz, intr_dict, synth_frame
+from helpers import load_npz, intr_dict, synth_frame, oracle_process_point_cloud
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,11 +34,22 @@ def test_farthest_point_sampling_function():
     import pcp.dp3_point_cloud_processing as dp3
     rng = np.random.default_rng(40)
     pts = rng.uniform(-0.4, 0.4, (5000, 3))                       # float64 in, like np.asarray(pcd.points)
-    sampled, idx = dp3.farthest_point_sampling(pts, num_points=2500, use_cuda=True)
-    ref_s, ref_i = cbind.fps(pts, 2500, 0)
-    assert sampled.dtype == np.float32 and idx.dtype == np.int64 and sampled.shape == (2500, 3)
-    np.testing.assert_array_equal(idx, ref_i)
-    np.testing.assert_array_equal(sampled, ref_s)
+    # use_cuda selects the arithmetic of the pytorch3d build the reference would run (DP3:11-16):
+    # True → CUDA kernel, nvcc-fused distance (dist_mode 1); False → CPU build, un-fused (dist_mode 0)
+    for use_cuda, mode in ((True, 1), (False, 0)):
+        sampled, idx = dp3.farthest_point_sampling(pts, num_points=2500, use_cuda=use_cuda)
+        ref_s, ref_i = cbind.fps(pts, 2500, mode)
+        assert sampled.dtype == np.float32 and idx.dtype == np.int64 and sampled.shape == (2500, 3)
+        np.testing.assert_array_equal(idx, ref_i)
+        np.testing.assert_array_equal(sampled, ref_s)
+    # a 0.1-spaced lattice has ties in exact arithmetic that the two roundings break differently: here the mapping matters
+    g = np.stack(np.meshgrid(np.arange(20), np.arange(20), np.arange(10), indexing="ij"), -1).reshape(-1, 3)
+    lat = g[np.random.default_rng(0).permutation(len(g))] * 0.1 + 0.03
+    i0, i1 = cbind.fps(lat, 500, 0)[1], cbind.fps(lat, 500, 1)[1]
+    assert (i0 != i1).sum() > 100
+    np.testing.assert_array_equal(dp3.farthest_point_sampling(lat, 500, use_cuda=True)[1], i1)
+    np.testing.assert_array_equal(dp3.farthest_point_sampling(lat, 500, use_cuda=False)[1], i0)
+    np.testing.assert_array_equal(dp3.farthest_point_sampling(lat, 500)[1], i0)           # DP3:7 default: use_cuda=False
     with pytest.raises(ValueError):
         dp3.farthest_point_sampling(np.zeros((0, 3)), 8)
 
@@ -48,16 +59,47 @@ def test_process_point_cloud_matches_oracle_incl_padding():
     rng = np.random.default_rng(41)
     xyz = rng.uniform(-0.3, 0.8, (30000, 3))
     rgb = rng.integers(0, 256, (30000, 3)) / 255.0
-    got_xyz, got_rgb = dp3.process_point_cloud(xyz, rgb, verbose=False)
-    ref_xyz, ref_rgb, _ = R.process_point_cloud(xyz, rgb)
+    got_xyz, got_rgb = dp3.process_point_cloud(xyz, rgb, verbose=False)          # default = the reference's use_cuda=True
+    ref_xyz, ref_rgb, _ = oracle_process_point_cloud(xyz, rgb, dist_mode=1)
+    np.testing.assert_array_equal(got_xyz, ref_xyz)
+    np.testing.assert_array_equal(got_rgb, ref_rgb)
+    got_xyz, got_rgb = dp3.process_point_cloud(xyz, rgb, verbose=False, use_cuda=False)
+    ref_xyz, ref_rgb, _ = R.process_point_cloud(xyz, rgb)                        # numpy restatement, un-fused
     np.testing.assert_array_equal(got_xyz, ref_xyz)
     np.testing.assert_array_equal(got_rgb, ref_rgb)
     # fewer than 2500 points survive → -1 padding → numpy negative index → last cropped colour (DP3:48)
     got_xyz, got_rgb = dp3.process_point_cloud(xyz[:3000], rgb[:3000], verbose=False)
-    ref_xyz, ref_rgb, ref_idx = R.process_point_cloud(xyz[:3000], rgb[:3000])
+    ref_xyz, ref_rgb, ref_idx = oracle_process_point_cloud(xyz[:3000], rgb[:3000], dist_mode=1)
     assert (ref_idx < 0).any()
     np.testing.assert_array_equal(got_xyz, ref_xyz)
     np.testing.assert_array_equal(got_rgb, ref_rgb)
+
+
+@pytest.mark.parametrize("name", ["stage2_frame_120x160.npz", "stage2_padded_48x64.npz", "stage2_boundary.npz"])
+def test_stage2_matches_reference_golden(name):
+    """Fixtures produced by calling the reference's own process_point_cloud (tests/golden/make_golden_stage2.py):
+    crop DP3:35-42, float32 cast DP3:10 and gather DP3:48 are the reference's lines; its sampler was a recorder that
+    scripted the indices with the oracle's un-fused FPS, so use_cuda=False is the mode to compare in."""
+    import torch
+    import pcp.dp3_point_cloud_processing as dp3
+    from pcp import ops
+    g = load_npz(name)
+    lo = [w[0] for w in R.WORK_SPACE]; hi = [w[1] for w in R.WORK_SPACE]
+    xyz = torch.from_numpy(g["pc_xyz"]).cuda(); rgb = torch.from_numpy(g["pc_rgb"]).cuda()
+    o64, o32, orgb, m = ops.crop_compact(xyz, rgb, lo, hi)                        # pcp_crop_compact
+    assert m == g["fps_in"].shape[0]
+    np.testing.assert_array_equal(o32.cpu().numpy(), g["fps_in"])                 # crop + DP3:10 cast, bit-exact
+    off = torch.tensor([0, xyz.shape[0]], dtype=torch.int64, device="cuda")
+    _, b32, brgb, boff = ops.crop_compact_batched(xyz, rgb, off, lo, hi)          # pcp_crop_compact_batched
+    assert boff.cpu().tolist() == [0, m]
+    np.testing.assert_array_equal(b32[:m].cpu().numpy(), g["fps_in"])
+    moff = torch.tensor([0, m], dtype=torch.int64, device="cuda")
+    idx = torch.from_numpy(g["idx"][None]).cuda()
+    got = ops.gather_rgb(orgb.float().contiguous(), moff, idx, True)             # pcp_gather_rgb, -1 → last row
+    np.testing.assert_array_equal(got[0].cpu().numpy(), g["out_rgb"].astype(np.float32))
+    got_xyz, got_rgb = dp3.process_point_cloud(g["pc_xyz"], g["pc_rgb"], verbose=False, use_cuda=False)
+    np.testing.assert_array_equal(got_xyz, g["out_xyz"])
+    np.testing.assert_array_equal(got_rgb, g["out_rgb"])                          # f64 colours, as the reference returns
 
 
 def _make_bag_tree(root, bag, n_frames, H=60, W=80):
@@ -108,7 +150,7 @@ def test_stage1_script_then_stage2_cli_end_to_end(tmp_path):
     assert sorted(os.listdir(out_dir)) == [f"pc_{i:05d}_filtered.ply" for i in range(3)]
     for i in range(3):
         glob, col = ply.read_point_cloud(os.path.join(pcd_root, "global_frame", f"pc_{i:05d}.ply"))
-        ref_xyz, ref_rgb, _ = R.process_point_cloud(glob, col)
+        ref_xyz, ref_rgb, _ = oracle_process_point_cloud(glob, col, dist_mode=1)       # the CLI samples like use_cuda=True
         xyz, rgb = ply.read_point_cloud(os.path.join(out_dir, f"pc_{i:05d}_filtered.ply"))
         assert xyz.shape == (2500, 3)
         np.testing.assert_array_equal(xyz, ref_xyz.astype(np.float64))
@@ -141,10 +183,18 @@ def test_batched_crop_and_batched_stage2_equal_the_per_cloud_path():
     nonempty = [c for c in clouds if len(c[0])]
     res = dp3.process_point_clouds_batched(nonempty)
     for (p, c), r in zip(nonempty, res):
-        ref_xyz, ref_rgb, _ = R.process_point_cloud(p, c)
+        ref_xyz, ref_rgb, _ = oracle_process_point_cloud(p, c, dist_mode=1)
         np.testing.assert_array_equal(r[0], ref_xyz)
         np.testing.assert_array_equal(r[1], ref_rgb)                                       # incl. -1 padding → last colour
     assert dp3.process_point_clouds_batched([(np.full((4, 3), 9.0), np.zeros((4, 3)))]) == [None]
+    # a mixed batch whose LAST clouds crop to nothing: they come back as None, the others are unaffected
+    outside = (np.full((7, 3), 9.0), np.zeros((7, 3)))
+    mixed = dp3.process_point_clouds_batched([nonempty[0], outside, nonempty[2], outside, outside], use_cuda=False)
+    assert mixed[1] is None and mixed[3] is None and mixed[4] is None
+    for j, k in ((0, 0), (2, 2)):
+        ref_xyz, ref_rgb, _ = R.process_point_cloud(*nonempty[k])
+        np.testing.assert_array_equal(mixed[j][0], ref_xyz)
+        np.testing.assert_array_equal(mixed[j][1], ref_rgb)
 
 
 def test_plain_c_client_of_the_abi(tmp_path):

@@ -12,11 +12,12 @@ from helpers import synth_frame
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_rows(frames, intr, K):
+def _oracle_rows(frames, intr, K, dist_mode=1):
+    """dist_mode 1: the runner samples the way the loop it replaces does (use_cuda=True, DP3:47)."""
     po = cbind.make_params(intr, intr, apply_crop=1)
     rows, counts = [], []
     for d, c in frames:
-        r = cbind.frame_pipeline(d, c, po, K, 0)
+        r = cbind.frame_pipeline(d, c, po, K, dist_mode)
         rows.append(cbind.pack_dp3(r["xyz"], r["rgb"]))
         counts.append(r["M"])
     return np.stack(rows), np.array(counts)
@@ -71,7 +72,7 @@ def test_direct_zarr_equals_ply_route_rows(tmp_path):
     # rows == what the PLY route (XPC → PLY → DP3 → PLY → CHK:134-144) yields for the same frames
     po = cbind.make_params(intr, intr, apply_crop=1)
     for t, (d, c) in enumerate(all_frames):
-        r = cbind.frame_pipeline(d, c, po, K, 0)
+        r = cbind.frame_pipeline(d, c, po, K, 1)
         np.testing.assert_array_equal(got["point_cloud"][t], R.dp3_rows(r["xyz"], r["rgb"]))
 
 

@@ -178,6 +178,6 @@ def test_filter_point_clouds_cli_runs_config3_filters_on_a_ply_directory(tmp_pat
         v = cbind.voxel_downsample(xyz[m], ply.read_point_cloud(str(src / f"pc_{i:05d}.ply"))[1][m].astype(np.float32), 0.01)
         s = cbind.statistical_outlier(v["xyz64"], 20, 2.0)
         pts = v["xyz64"][s["keep"]].astype(np.float32)
-        ref_xyz, ref_idx = cbind.fps(pts, 512, 0)
+        ref_xyz, ref_idx = cbind.fps(pts, 512, 1)            # the CLI samples like the reference: use_cuda=True → fused
         got, _ = ply.read_point_cloud(str(dst / f"pc_{i:05d}_filtered.ply"))
         np.testing.assert_array_equal(got, ref_xyz.astype(np.float64))

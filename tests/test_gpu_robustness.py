@@ -1,0 +1,199 @@
+"""GPU (-m gpu): the places where the library must fail loudly instead of silently — understated bounds, capacity
+overflow, empty crops in the zarr route — plus the multi-rank / multi-device plumbing (two ranks sharing cuda:0,
+since the round's GPU box has one card)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind, numpy_ref as R
+from pcp import _ffi, ops
+from helpers import synth_frame, bench_intr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PCP = os.path.join(ROOT, "point-cloud-processing_amd", "pcp")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_fps_cloud_above_max_pts_is_flagged_not_skipped(algo):
+    """pcp_fps_batched with an understated max_pts: the oversized cloud gets an all -1 row and the overflow flag;
+    the other clouds are sampled as usual; no output row is left unwritten (idx is pre-filled with a canary)."""
+    rng = np.random.default_rng(61)
+    sizes = [5000, 70000, 3000]                                     # 70000 > 65536: beyond the only launched shape
+    clouds = [rng.uniform(-0.5, 0.5, (m, 3)).astype(np.float32) for m in sizes]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    K = 64
+    plan = ops.Fps(3, int(off[-1]), 6000, K, "cuda", 0, algo)       # caller claims no cloud exceeds 6000 points
+    plan.idx.fill_(-7); plan.xyz.fill_(7.0)
+    xyz, idx = plan.run(dev(np.concatenate(clouds)), dev(off))
+    torch.cuda.synchronize()
+    idx, xyz = idx.cpu().numpy(), xyz.cpu().numpy()
+    if algo == 2:
+        assert int(plan.overflow.item()) == 1
+        assert (idx[1] == -1).all() and (xyz[1] == 0).all()
+    else:                                                           # brute force has no size classes: it just samples
+        assert int(plan.overflow.item()) == 0
+        np.testing.assert_array_equal(idx[1], cbind.fps(clouds[1], K, 0)[1])
+    for b in (0, 2):
+        np.testing.assert_array_equal(idx[b], cbind.fps(clouds[b], K, 0)[1])
+    assert (idx != -7).all()
+    # an honest bound clears the flag again
+    plan2 = ops.Fps(3, int(off[-1]), 70000, K, "cuda", 0, algo)
+    _, idx2 = plan2.run(dev(np.concatenate(clouds)), dev(off))
+    assert int(plan2.overflow.item()) == 0
+    np.testing.assert_array_equal(idx2[1].cpu().numpy(), cbind.fps(clouds[1], K, 0)[1])
+
+
+def test_fps_offsets_past_total_pts_are_flagged():
+    rng = np.random.default_rng(62)
+    pts = rng.uniform(-0.5, 0.5, (9000, 3)).astype(np.float32)
+    off = np.array([0, 4000, 9000, 20000], np.int64)                # third cloud claims rows that do not exist
+    for algo in (1, 2):
+        plan = ops.Fps(3, 9000, 20000, 32, "cuda", 0, algo)
+        plan.idx.fill_(-7)
+        _, idx = plan.run(dev(pts), dev(off))
+        idx = idx.cpu().numpy()
+        assert int(plan.overflow.item()) == 1
+        assert (idx[2] == -1).all()
+        np.testing.assert_array_equal(idx[0], cbind.fps(pts[:4000], 32, 0)[1])
+        np.testing.assert_array_equal(idx[1], cbind.fps(pts[4000:], 32, 0)[1])
+
+
+def test_frame_pipeline_with_undersized_capacity_reports_instead_of_faulting():
+    """Stage 1 with too small a row capacity leaves the TRUE counts in offsets; FPS and the gather must not follow
+    them out of bounds: the frames that fit are exact, the others come back as -1 / zero rows, check() raises."""
+    intr = bench_intr(120, 160, 151.25)
+    frames = [synth_frame(70 + i, 120, 160) for i in range(4)]
+    p = _ffi.make_params(intr, intr, apply_crop=True)
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    refs = [cbind.frame_pipeline(d, c, po, 128, 0) for d, c in frames]
+    counts = [r["M"] for r in refs]
+    cap_pf = (counts[0] + counts[1] + counts[2] // 2) // 4 + 1      # room for two frames and a bit
+    pipe = ops.FramePipeline(4, 120, 160, 128, p, "cuda", cap_per_frame=cap_pf)
+    assert pipe.stage1.cap < sum(counts) and pipe.stage1.cap >= counts[0] + counts[1]
+    depth = dev(np.stack([f[0] for f in frames])); rgb = dev(np.stack([f[1] for f in frames]))
+    xyz, col, idx, off = pipe.run(depth, rgb)
+    torch.cuda.synchronize()
+    assert np.diff(off.cpu().numpy()).tolist() == counts             # true counts survive
+    assert int(pipe.stage1.overflow.item()) == 1 and int(pipe.fps.overflow.item()) == 1
+    with pytest.raises(_ffi.PcpError):
+        pipe.check()
+    for b in (0, 1):
+        np.testing.assert_array_equal(idx[b].cpu().numpy(), refs[b]["idx"])
+        np.testing.assert_array_equal(col[b].cpu().numpy(), refs[b]["rgb"])
+    for b in (2, 3):
+        assert (idx[b] == -1).all() and (xyz[b] == 0).all() and (col[b] == 0).all()
+    ok = ops.FramePipeline(4, 120, 160, 128, p, "cuda")
+    ok.run(depth, rgb)
+    ok.check()
+
+
+def _make_traj(root, name, n, H=60, W=80, empty_at=None, missing=None):
+    from PIL import Image
+    ext = os.path.join(root, name, "extracted_data", name)
+    os.makedirs(os.path.join(ext, "camera", "rgb")); os.makedirs(os.path.join(ext, "camera", "depth"))
+    intr = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    json.dump({"color": intr, "depth": intr}, open(os.path.join(ext, "intrinsics.json"), "w"))
+    frames = []
+    for i in range(n):
+        d, c = synth_frame(sum(map(ord, name)) % 1000 + i, H, W)
+        if i == empty_at:
+            d = np.full_like(d, 4.0)                                 # valid depth, but far outside the workspace box
+        if i != missing:
+            np.save(os.path.join(ext, "camera", "depth", f"depth_{i:05d}.npy"), d)
+        Image.fromarray(c).save(os.path.join(ext, "camera", "rgb", f"rgb_{i:05d}.png"))
+        frames.append((d, c))
+    st = np.arange(n * 7, dtype=float).reshape(n, 7)
+    np.savetxt(os.path.join(ext, "states.txt"), st); np.savetxt(os.path.join(ext, "actions.txt"), st * 0.5)
+    return intr, frames
+
+
+def test_build_zarr_gpu_skips_a_trajectory_with_an_empty_crop(tmp_path, capsys):
+    """The reference's filter step dies on a frame with no point in the workspace (pytorch3d raises, DP3:47), its
+    driver moves on (S2:15-18) and chunking_data.py then skips the trajectory for its missing clouds (CHK:127-132).
+    --source gpu must not write zero rows for such a frame: same skip, same message."""
+    from pcp import build_zarr, zarr_store
+    root = str(tmp_path / "processed")
+    intr, good = _make_traj(root, "traj_a", 4)
+    _make_traj(root, "traj_b", 5, empty_at=2)
+    _make_traj(root, "traj_c", 4, missing=1)                         # a frame without depth file: 3 clouds for 4 states
+    out = str(tmp_path / "dp3.zarr")
+    total, eps = build_zarr.build(root, out, source="gpu", K=64, ext=R.BASE_TO_EXT_CAM_S1.reshape(4, 4))
+    log = capsys.readouterr().out
+    assert (total, eps) == (4, 1)
+    assert "Warning: traj_b has 5 states but 2 point clouds. Skipping." in log
+    assert "Warning: traj_c has 4 states but 3 point clouds. Skipping." in log
+    got = zarr_store.read_dp3_dataset(out)
+    np.testing.assert_array_equal(got["episode_ends"], [4])
+    po = cbind.make_params(intr, intr, apply_crop=1)
+    for t, (d, c) in enumerate(good):
+        r = cbind.frame_pipeline(d, c, po, 64, 1)
+        np.testing.assert_array_equal(got["point_cloud"][t], R.dp3_rows(r["xyz"], r["rgb"]))
+
+
+def test_two_ranks_sharing_the_gpu_build_the_same_store_and_bench_reports_two(tmp_path):
+    """BASELINE configs[3] rehearsed on the one card this round has: two torch.distributed ranks (gloo rendezvous,
+    both on cuda:0) run build_zarr --source gpu over 4 small episodes and the weak-scaling bench; the store must
+    equal the single-process one and the bench line must report n_gpus = 2.  Unmeasured on 8 GPUs (no such node)."""
+    from pcp import build_zarr, zarr_store
+    root = str(tmp_path / "processed")
+    for name, n in (("ep0", 5), ("ep1", 3), ("ep2", 6), ("ep3", 4)):
+        _make_traj(root, name, n)
+    one = str(tmp_path / "one.zarr")
+    total, eps = build_zarr.build(root, one, source="gpu", K=96)
+    assert (total, eps) == (18, 4)
+    port = str(29500 + (os.getpid() + 11) % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, WORLD_SIZE="2")
+    two = str(tmp_path / "two.zarr")
+    procs = [subprocess.Popen([sys.executable, os.path.join(PCP, "build_zarr.py"), "--data_root", root, "--out_zarr", two,
+                               "--source", "gpu", "--num_points", "96"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    a, b = zarr_store.read_dp3_dataset(one), zarr_store.read_dp3_dataset(two)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    port = str(29500 + (os.getpid() + 12) % 2000)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--frames", "32", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["verified_vs_oracle"] is True and line["config"]["frames_per_step_per_gpu"] == 32
+
+
+def test_second_device_gives_the_same_results_as_the_first():
+    """tensors on cuda:1 must be processed on cuda:1 (libpcp launches on the current device).  Needs two
+    GPUs; skipped on the one-card box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    intr = bench_intr(120, 160, 151.25)
+    frames = [synth_frame(80 + i, 120, 160) for i in range(3)]
+    p = _ffi.make_params(intr, intr, apply_crop=True)
+    depth = np.stack([f[0] for f in frames]); rgb = np.stack([f[1] for f in frames])
+    outs = []
+    for d in ("cuda:0", "cuda:1"):
+        pipe = ops.FramePipeline(3, 120, 160, 128, p, d)
+        xyz, col, idx, off = pipe.run(torch.from_numpy(depth).to(d), torch.from_numpy(rgb).to(d))
+        torch.cuda.synchronize(d)
+        assert idx.device == torch.device(d)
+        outs.append((xyz.cpu().numpy(), col.cpu().numpy(), idx.cpu().numpy(), off.cpu().numpy()))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    from pcp.episode import EpisodeRunner
+    r0, c0 = EpisodeRunner(120, 160, 128, p, device="cuda:0", chunk=2).run_arrays(depth, rgb)
+    r1, c1 = EpisodeRunner(120, 160, 128, p, device="cuda:1", chunk=2).run_arrays(depth, rgb)
+    np.testing.assert_array_equal(r0, r1); np.testing.assert_array_equal(c0, c1)

@@ -99,6 +99,28 @@ def test_dropin_modules_keep_the_reference_signatures():
     assert float(xpc.T_DEPTH_TO_COLOR[0, 3]) == -0.05900000035762787
 
 
+def test_fps_precision_follows_the_reference_device_switch(monkeypatch):
+    """DP3:11-16: use_cuda=True → pytorch3d's CUDA kernel (nvcc-fused distance, dist_mode 1); False → its CPU build
+    (un-fused, dist_mode 0).  DP3:47 hard-codes True, so that is the default of everything that replaces the loop."""
+    import pcp.dp3_point_cloud_processing as dp3
+    from pcp import ops
+    from pcp.episode import EpisodeRunner
+    monkeypatch.delenv("PCP_DIST_MODE", raising=False)
+    assert ops.dist_mode_for(True) == 1 and ops.dist_mode_for(False) == 0
+    assert dp3.REFERENCE_USE_CUDA is True
+    assert inspect.signature(dp3.process_point_cloud).parameters["use_cuda"].default is True
+    assert inspect.signature(dp3.process_point_clouds_batched).parameters["use_cuda"].default is True
+    assert inspect.signature(dp3.farthest_point_sampling).parameters["use_cuda"].default is False     # DP3:7
+    assert inspect.signature(EpisodeRunner.__init__).parameters["dist_mode"].default is None           # → dist_mode_for(True)
+    monkeypatch.setenv("PCP_DIST_MODE", "0")
+    assert ops.dist_mode_for(True) == 0
+    monkeypatch.setenv("PCP_DIST_MODE", "1")
+    assert ops.dist_mode_for(False) == 1
+    monkeypatch.setenv("PCP_DIST_MODE", "2")
+    with pytest.raises(ValueError):
+        ops.dist_mode_for(True)
+
+
 def test_stage2_driver_skips_and_reports(tmp_path, capsys):
     import pcp.pipeline_stage2_filter as s2
     (tmp_path / "bagA").mkdir()                      # no point_clouds/global_frame

@@ -86,6 +86,39 @@ def test_full_frame_digest_numpy_restatement():
     assert sha(out["pts_g"]) == dg["pts_g_sha"]
 
 
+STAGE2 = ["stage2_frame_120x160.npz", "stage2_padded_48x64.npz", "stage2_boundary.npz"]
+
+
+@pytest.mark.parametrize("name", STAGE2)
+def test_stage2_restatement_matches_reference(name):
+    """Fixtures made by calling the reference's own process_point_cloud (tests/golden/make_golden_stage2.py):
+    the crop DP3:35-42, the float32 cast DP3:10 and the gather DP3:48 are the reference's lines; the indices
+    were scripted by the oracle's FPS (pytorch3d absent), so `idx` itself is not a reference output."""
+    g = load_npz(name)
+    lo = [w[0] for w in R.WORK_SPACE]
+    hi = [w[1] for w in R.WORK_SPACE]
+    with np.errstate(all="ignore"):
+        xyz, rgb, m = R.workspace_crop(g["pc_xyz"], g["pc_rgb"])
+        np.testing.assert_array_equal(xyz.astype(np.float32), g["fps_in"])             # crop + DP3:10 cast
+        np.testing.assert_array_equal(cbind.crop_mask(g["pc_xyz"], lo, hi), m)
+    assert g["fps_in"].dtype == np.float32 and g["out_rgb"].dtype == np.float64 and g["idx"].shape == (2500,)
+    np.testing.assert_array_equal(R.gather_rgb(rgb, g["idx"]), g["out_rgb"])           # DP3:48 incl. -1 → last row
+    np.testing.assert_array_equal(cbind.gather_rgb(rgb.astype(np.float32), g["idx"], 1),
+                                  g["out_rgb"].astype(np.float32))
+    M = g["fps_in"].shape[0]
+    if M < 2500:
+        assert (g["idx"][M:] == -1).all()
+        np.testing.assert_array_equal(g["out_rgb"][M:], np.broadcast_to(rgb[-1], (2500 - M, 3)))
+    with np.errstate(all="ignore"):
+        s, c, idx = R.process_point_cloud(g["pc_xyz"], g["pc_rgb"])
+    np.testing.assert_array_equal(idx, g["idx"])
+    np.testing.assert_array_equal(s, g["out_xyz"])
+    np.testing.assert_array_equal(c, g["out_rgb"])
+    s1, i1 = cbind.fps(g["fps_in"], 2500, 0)
+    np.testing.assert_array_equal(i1, g["idx"])
+    np.testing.assert_array_equal(s1, g["out_xyz"])
+
+
 def test_crop_mask_strict_and_c_equals_numpy():
     lo = [w[0] for w in R.WORK_SPACE]
     hi = [w[1] for w in R.WORK_SPACE]

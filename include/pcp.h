@@ -22,8 +22,9 @@
  *     the device that owns `stream` and the buffers current (hipSetDevice / torch.cuda.device)
  *     before the call; the library never changes the current device.
  *   - No mutable state is shared between calls: calls on different streams / workspaces are
- *     independent and thread-safe.  (One process-wide footnote: the FPS shapes that need more than
- *     48 KB of LDS set that per-kernel attribute, to the same value, on every launch.)
+ *     independent and thread-safe.  (Two process-wide footnotes: the FPS shapes that need more than
+ *     48 KB of LDS set that per-kernel attribute, to the same value, on every launch; and
+ *     pcp_fps_batched_static owns one static device buffer per GPU, shared by all its calls there.)
  */
 #ifndef PCP_H
 #define PCP_H
@@ -235,6 +236,22 @@ int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t tot
                     int64_t max_pts, int K, int dist_mode, int algo,
                     int64_t* idx, float* out_xyz, int32_t* overflow,
                     void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * pcp_fps_batched without a workspace argument and WITHOUT ANY ALLOCATION.  It has no counterpart in the
+ * reference: it exists for callers that cannot allocate device memory — code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  The sorted-record / min-distance workspace is a static
+ * device array inside the library (32 MiB per GPU the library runs on, held until the process ends), so
+ *   total_pts <= PCP_FPS_STATIC_MAX_PTS, else PCP_ERR_CAPACITY (use pcp_fps_batched with your own workspace).
+ * Inputs, outputs, `overflow`, results and every other rule are those of pcp_fps_batched; the call itself makes
+ * no hipMalloc / hipFree / allocating library call.  All calls on one GPU share that GPU's array: calls that
+ * overlap on the same GPU (different streams or threads) race — serialise them.  Nothing has to be cleared
+ * between calls (a launch rewrites every row it reads).
+ */
+#define PCP_FPS_STATIC_MAX_PTS 1600000
+int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
+                           int64_t max_pts, int K, int dist_mode, int algo,
+                           int64_t* idx, float* out_xyz, int32_t* overflow, void* stream);
 
 /*
  * Colour gather pc_rgb[idx], DP3:48.

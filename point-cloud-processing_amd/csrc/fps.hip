@@ -15,6 +15,7 @@
 // key 0 means "no candidate".
 #include "pcp_internal.h"
 #include <float.h>
+#include <pthread.h>
 #include <type_traits>
 
 template <int MODE>
@@ -1148,4 +1149,58 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
 {
     return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
                             ws_bytes, (hipStream_t)stream);
+}
+
+// ---- no-allocation twin of pcp_fps_batched -----------------------------------------------------------------------
+// For callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+// it): the sorted-record / min-distance workspace lives in a file-scope device array instead of a caller buffer.
+// Every GPU the library runs on holds its own copy of the array (32 MiB) at its own address until the process ends.
+// In host code the array's NAME is only a stand-in; the device address comes from hipGetSymbolAddress, once per
+// device, with that device current, and only that pointer is ever handed to kernels.
+#define PCP_FPS_STATIC_BYTES (32u * 1024u * 1024u)
+static __device__ __align__(256) unsigned char pcp_fps_scratch[PCP_FPS_STATIC_BYTES];
+
+#define PCP_FPS_STATIC_MAX_DEVICES 64
+static void* g_fps_scratch_ptr[PCP_FPS_STATIC_MAX_DEVICES];       // device address of pcp_fps_scratch on device i, or NULL
+static pthread_mutex_t g_fps_scratch_lock = PTHREAD_MUTEX_INITIALIZER;
+
+// device address of the current device's copy of the scratch array (resolved on the first call per device)
+static int fps_static_scratch(void** out)
+{
+    int dev = -1;
+    PCP_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= PCP_FPS_STATIC_MAX_DEVICES) return PCP_ERR_NO_DEVICE;
+    pthread_mutex_lock(&g_fps_scratch_lock);
+    void* p = g_fps_scratch_ptr[dev];
+    if (!p) {
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(pcp_fps_scratch));
+        if (e != hipSuccess || !p || ((uintptr_t)p & 255)) {
+            (void)hipGetLastError();
+            pthread_mutex_unlock(&g_fps_scratch_lock);
+            return PCP_ERR_LAUNCH;
+        }
+        g_fps_scratch_ptr[dev] = p;
+    }
+    pthread_mutex_unlock(&g_fps_scratch_lock);
+    *out = p;
+    return PCP_OK;
+}
+
+static_assert(((size_t)PCP_FPS_STATIC_MAX_PTS * 16 + 255) / 256 * 256 + ((size_t)PCP_FPS_STATIC_MAX_PTS * 4 + 255) / 256 * 256 + 256
+                  <= PCP_FPS_STATIC_BYTES,
+              "PCP_FPS_STATIC_MAX_PTS points must fit the static scratch array");
+
+extern "C" int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
+                                      int64_t max_pts, int K, int dist_mode, int algo, int64_t* idx,
+                                      float* out_xyz, int32_t* overflow, void* stream)
+{
+    if (total_pts > (int64_t)PCP_FPS_STATIC_MAX_PTS) return PCP_ERR_CAPACITY;     // beyond the static scratch: use pcp_fps_batched
+    if (total_pts < 0) return PCP_ERR_INVALID_ARG;
+    void* ws = nullptr;
+    const int rc = fps_static_scratch(&ws);
+    if (rc != PCP_OK) return rc;
+    // Nothing in the workspace has to start at zero: every launch rewrites the records and min-distances of the rows
+    // it reads before it reads them, so the previous call's contents are never observed.
+    return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
+                            pcp_fps_workspace_bytes(B, total_pts, max_pts, K, algo), (hipStream_t)stream);
 }

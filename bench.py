@@ -220,8 +220,6 @@ def main():
     for s_ in streams:
         s_.wait_stream(torch.cuda.current_stream(dev))
 
-    L = _ffi.load_library()
-    ptr = ops._ptr
     step_no = [0]
 
     def step(ev=None, use=None):
@@ -236,8 +234,7 @@ def main():
             f.enqueue(out["xyz32"], offsets, pipe.stage1.cap)                    # pcp_fps_batched
             if ev is not None:
                 ev[1].record(streams[j])
-            ops._call(dev, L.pcp_gather_rgb, ptr(out["rgb32"]), ptr(offsets), pipe.stage1.cap, ptr(f.idx), f.B, f.K, 1,
-                      ptr(pipe.rgb_out))
+            pipe.gather(depth, rgb)                                              # pcp_gather_rgb_pixels
 
     def barrier():
         if world > 1:

@@ -266,6 +266,18 @@ int pcp_gather_rgb(const float* rgb, const int64_t* offsets, int64_t total_pts, 
                    int B, int K, int compat_neg_index, float* out, void* stream);
 
 /*
+ * The same gather with the colour lookup fused in, for clouds made by pcp_backproject_align_crop: the colours of
+ * the K sampled points are evaluated from each point's SOURCE PIXEL (`pix` as written by that call; deproject +
+ * align_colors, XPC:58-78, for those points only) instead of being read from a (total,3) colour array — so stage 1
+ * need not compute, store or gather a colour for the other M-K points of every cloud (pass rgb32 = NULL there).
+ * Values are bit-identical to pcp_gather_rgb over rgb32.  depth / rgb / p are the stage-1 inputs of the same B
+ * frames (single camera); pix (total_pts) i32; everything else as pcp_gather_rgb.
+ */
+int pcp_gather_rgb_pixels(const float* depth, const uint8_t* rgb, int B, int H, int W, int Hc, int Wc,
+                          const pcp_params* p, const int32_t* pix, const int64_t* offsets, int64_t total_pts,
+                          const int64_t* idx, int K, int compat_neg_index, float* out, void* stream);
+
+/*
  * (K,6) rows exactly as chunking_data.py:134-144 stacks them for the zarr
  * `data/point_cloud` array (CHK:195): [x, y, z, r*255, g*255, b*255] as f32.
  *   xyz (B,K,3) f32, rgb (B,K,3) f32 in [0,1] → out (B,K,6) f32

@@ -149,13 +149,17 @@ k1_dense(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
 // points) the wave falls back to evaluating every pixel in place.
 #define K1_PACK_MAX 128
 
+// CROP / TFMA: p->apply_crop / p->transform_fma as template parameters — with run-time switches the compiler kept
+// both forms of every transform row behind branches and, short of scalar registers, re-fetched the parameter block from
+// the kernel-argument segment inside the pixel loop (six scalar loads with a full wait per 64 pixels).
+template <bool CROP, bool TFMA>
 __global__ void __launch_bounds__(256)
 k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
          int Wc, DevParams P, unsigned long long* __restrict__ masks, int* __restrict__ tile_cnt,
          int tiles, int b_first, int b_stride)
 {
     __shared__ int wave_cnt[4];
-    __shared__ double pk_cam[4][K1_PACK_MAX][3];
+    __shared__ double pk_cam[4][3][K1_PACK_MAX];                  // SoA: consecutive survivors 8 bytes apart, no bank conflicts
     __shared__ unsigned char pk_pos[4][K1_PACK_MAX];
     __shared__ unsigned long long pk_mask[4][4];
     const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
@@ -169,28 +173,50 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
     double cam[4][3];
     unsigned long long pre[4];
     int npre = 0;
+    // (row, column) of the lane's first pixel by one division; the next rounds are 64 pixels further on
+    int pv, pu;
+    pcp_divmod(tile * PCP_TILE + wave * 256 + lane, W, invW, &pv, &pu);
+    const int dv64 = 64 / W, du64 = 64 - dv64 * W;                    // 64 = dv64*W + du64 (scalar)
+    // Phase by phase over the wave's four rounds instead of pixel by pixel: each phase needs only a few of the ~40
+    // FP64 parameters, so they stay in scalar registers instead of being re-fetched for every round.
+    bool ok[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < 4; ++r) {                                     // deproject, XPC:58-64
         const int i = tile * PCP_TILE + (wave * 4 + r) * 64 + lane;
-        int ok = 0;
-        cam[r][0] = cam[r][1] = cam[r][2] = 0.0;
-        if (i < HW) {
-            int pv, pu;
-            pcp_divmod(i, W, invW, &pv, &pu);
-            const float d = dframe[i];
-            const double z = (double)d;
-            cam[r][0] = (((double)pu - P.dcx) * z) / P.dfx;            // XPC:62
-            cam[r][1] = (((double)pv - P.dcy) * z) / P.dfy;            // XPC:63
-            cam[r][2] = z;
-            ok = (d > P.z_min) && (d < P.z_max);                      // XPC:109 (f32 compares)
-            if (P.apply_crop) {
-                double base[3];
-                rigid3(P.E, P.transform_fma, cam[r][0], cam[r][1], cam[r][2], base);   // XPC:119
-                ok = ok && base[0] > P.lo[0] && base[0] < P.hi[0] && base[1] > P.lo[1] && base[1] < P.hi[1] &&
-                     base[2] > P.lo[2] && base[2] < P.hi[2];          // DP3:35-39
+        if (r > 0) {
+            pu += du64; pv += dv64;
+            if (pu >= W) { pu -= W; pv += 1; }
+        }
+        const float d = i < HW ? dframe[i] : 0.0f;                    // 0 fails the range test below
+        const double z = (double)d;
+        cam[r][0] = (((double)pu - P.dcx) * z) / P.dfx;                // XPC:62
+        cam[r][1] = (((double)pv - P.dcy) * z) / P.dfy;                // XPC:63
+        cam[r][2] = z;
+        ok[r] = (i < HW) & (d > P.z_min) & (d < P.z_max);             // XPC:109 (f32 compares)
+    }
+    if (CROP) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                 // one row of XPC:119 and its two DP3:35-39 compares
+            const double* q = P.E + 4 * c;
+            const double lo = P.lo[c], hi = P.hi[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double a;
+                if (TFMA) {
+                    a = q[0] * cam[r][0];
+                    a = fma(q[1], cam[r][1], a);
+                    a = fma(q[2], cam[r][2], a);
+                    a = fma(q[3], 1.0, a);
+                } else {
+                    a = ((q[0] * cam[r][0] + q[1] * cam[r][1]) + q[2] * cam[r][2]) + q[3];
+                }
+                ok[r] = ok[r] & (a > lo) & (a < hi);
             }
         }
-        pre[r] = __ballot(ok);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pre[r] = __ballot(ok[r]);
         npre += __popcll(pre[r]);
     }
 
@@ -202,13 +228,13 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
         for (int r = 0; r < 4; ++r) {
             if ((pre[r] >> lane) & 1ull) {
                 const int c = off + __popcll(pre[r] & lt);
-                pk_cam[wave][c][0] = cam[r][0]; pk_cam[wave][c][1] = cam[r][1]; pk_cam[wave][c][2] = cam[r][2];
+                pk_cam[wave][0][c] = cam[r][0]; pk_cam[wave][1][c] = cam[r][1]; pk_cam[wave][2][c] = cam[r][2];
                 pk_pos[wave][c] = (unsigned char)(r * 64 + lane);
             }
             off += __popcll(pre[r]);
         }
         for (int c = lane; c < npre; c += 64) {                       // one wave: LDS accesses stay in program order
-            const double cc[3] = {pk_cam[wave][c][0], pk_cam[wave][c][1], pk_cam[wave][c][2]};
+            const double cc[3] = {pk_cam[wave][0][c], pk_cam[wave][1][c], pk_cam[wave][2][c]};
             float col[3];
             if (align_math<false>(P, cc, img, Hc, Wc, col)) {
                 const int p = pk_pos[wave][c];
@@ -310,6 +336,11 @@ __global__ void pcp_csr_offsets(const long long* __restrict__ offsets, int B,
 
 
 // ---- compaction pass 2: survivors only -----------------------------------------------------
+// TFMA: p->transform_fma as a template parameter (see k1_flags).  Every output is optional and only what is asked for
+// is computed: without rgb32 the colour-frame projection (more than half of the FP64 work and a scattered byte
+// gather) is skipped altogether — the pipeline then fetches the colours of the K sampled points only
+// (k1_gather_pixels below).
+template <bool TFMA>
 __global__ void __launch_bounds__(256)
 k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
            int Wc, DevParams P, const unsigned long long* __restrict__ masks,
@@ -334,6 +365,7 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
     const long long base = offsets[b] + tile_off[(size_t)b * tiles + tile];
     const float* dframe = depth + (size_t)b * HW;
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
+    const float invW = 1.0f / (float)W;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         int w = 0;
 #pragma unroll
@@ -343,16 +375,58 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
         const int i = tile * PCP_TILE + w * 64 + bit;
         const long long row = base + j;
         if (row >= cap) { if (overflow) *overflow = 1; continue; }
-        PixelOut o;
         int pv, pu;
-        pcp_divmod(i, W, 1.0f / (float)W, &pv, &pu);
-        pixel_math<true>(P, dframe[i], pu, pv, img, Hc, Wc, o);
-        if (xyz_cam64) { xyz_cam64[3 * row] = o.cam[0]; xyz_cam64[3 * row + 1] = o.cam[1]; xyz_cam64[3 * row + 2] = o.cam[2]; }
-        if (xyz64) { xyz64[3 * row] = o.base[0]; xyz64[3 * row + 1] = o.base[1]; xyz64[3 * row + 2] = o.base[2]; }
-        if (xyz32) { xyz32[3 * row] = (float)o.base[0]; xyz32[3 * row + 1] = (float)o.base[1]; xyz32[3 * row + 2] = (float)o.base[2]; }   // DP3:10
-        if (rgb32) { rgb32[3 * row] = o.col[0]; rgb32[3 * row + 1] = o.col[1]; rgb32[3 * row + 2] = o.col[2]; }
+        pcp_divmod(i, W, invW, &pv, &pu);
+        const double z = (double)dframe[i];
+        double cam[3];
+        cam[0] = (((double)pu - P.dcx) * z) / P.dfx;                  // XPC:62 multiply, then divide
+        cam[1] = (((double)pv - P.dcy) * z) / P.dfy;                  // XPC:63
+        cam[2] = z;
+        if (xyz_cam64) { xyz_cam64[3 * row] = cam[0]; xyz_cam64[3 * row + 1] = cam[1]; xyz_cam64[3 * row + 2] = cam[2]; }
+        if (xyz64 || xyz32) {
+            double g[3];
+            rigid3(P.E, TFMA, cam[0], cam[1], cam[2], g);             // XPC:119
+            if (xyz64) { xyz64[3 * row] = g[0]; xyz64[3 * row + 1] = g[1]; xyz64[3 * row + 2] = g[2]; }
+            if (xyz32) { xyz32[3 * row] = (float)g[0]; xyz32[3 * row + 1] = (float)g[1]; xyz32[3 * row + 2] = (float)g[2]; }   // DP3:10
+        }
+        if (rgb32) {
+            float col[3];
+            align_math<true>(P, cam, img, Hc, Wc, col);               // XPC:66-78 (the mask already holds proj)
+            rgb32[3 * row] = col[0]; rgb32[3 * row + 1] = col[1]; rgb32[3 * row + 2] = col[2];
+        }
         if (pix) pix[row] = i;
     }
+}
+
+// Colours of the SAMPLED points only: pc_rgb[idx] (DP3:48) evaluated from each selected point's source pixel —
+// deproject + align_colors (XPC:58-78) for K points per cloud instead of storing (and first computing) a colour for
+// every one of the cloud's M points.  Same arithmetic, same values as gathering rgb32.
+__global__ void __launch_bounds__(256)
+k1_gather_pixels(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc, int Wc,
+                 DevParams P, const int32_t* __restrict__ pix, const long long* __restrict__ offsets,
+                 long long total_pts, const long long* __restrict__ idx, int K, int compat_neg,
+                 float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long base = offsets[b], M = offsets[b + 1] - base;
+    long long i = idx[(size_t)b * K + k];
+    float* o = out + ((size_t)b * K + k) * 3;
+    if (i < 0) {
+        if (compat_neg && M > 0 && i + M >= 0) i += M;        // numpy negative indexing, DP3:48
+        else { o[0] = o[1] = o[2] = 0.f; return; }
+    }
+    if (i >= M || base < 0 || base + i >= total_pts) { o[0] = o[1] = o[2] = 0.f; return; }
+    const int p = pix[base + i];
+    if (p < 0 || p >= HW) { o[0] = o[1] = o[2] = 0.f; return; }
+    int pv, pu;
+    pcp_divmod(p, W, 1.0f / (float)W, &pv, &pu);
+    const double z = (double)depth[(size_t)b * HW + p];
+    const double cam[3] = {(((double)pu - P.dcx) * z) / P.dfx, (((double)pv - P.dcy) * z) / P.dfy, z};
+    float col[3];
+    align_math<true>(P, cam, rgb + (size_t)b * Hc * Wc * 3, Hc, Wc, col);
+    o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
 }
 
 // fused (all cameras of a frame) CSR offsets: every C-th entry of the per-image offsets
@@ -437,18 +511,38 @@ static int backproject_align_crop_impl(const float* depth, const uint8_t* rgb, i
         return PCP_OK;
     }
     dim3 grid(tiles, F);
-    for (int c = 0; c < C; ++c)
-        hipLaunchKernelGGL(k1_flags, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, pcp_to_dev(cams + c),
+    for (int c = 0; c < C; ++c) {
+        const bool crop = cams[c].apply_crop != 0, tfma = cams[c].transform_fma != 0;
+        auto kern = crop ? (tfma ? k1_flags<true, true> : k1_flags<true, false>)
+                         : (tfma ? k1_flags<false, true> : k1_flags<false, false>);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, pcp_to_dev(cams + c),
                            masks, tile_cnt, tiles, c, C);
+    }
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(B), dim3(256), 0, st, tile_cnt, tiles, frame_cnt);
     hipLaunchKernelGGL(pcp_scan_frames, dim3(1), dim3(256), 0, st, frame_cnt, B, (long long*)offsets);
     for (int c = 0; c < C; ++c)
-        hipLaunchKernelGGL(k1_scatter, grid, dim3(256), 0, st, depth, rgb, HW, W, Hc, Wc, pcp_to_dev(cams + c),
-                           masks, tile_cnt, (const long long*)offsets, tiles, xyz_cam64, xyz64, xyz32, rgb32,
-                           pix, (long long)cap, overflow, c, C);
+        hipLaunchKernelGGL(cams[c].transform_fma ? k1_scatter<true> : k1_scatter<false>, grid, dim3(256), 0, st, depth, rgb,
+                           HW, W, Hc, Wc, pcp_to_dev(cams + c), masks, tile_cnt, (const long long*)offsets, tiles,
+                           xyz_cam64, xyz64, xyz32, rgb32, pix, (long long)cap, overflow, c, C);
     if (fused_offsets)
         hipLaunchKernelGGL(k1_fused_offsets, dim3((F + 256) / 256), dim3(256), 0, st, (const long long*)offsets,
                            F, C, (long long*)fused_offsets);
+    return pcp_launch_status();
+}
+
+extern "C" int pcp_gather_rgb_pixels(const float* depth, const uint8_t* rgb, int B, int H, int W, int Hc, int Wc,
+                                     const pcp_params* p, const int32_t* pix, const int64_t* offsets,
+                                     int64_t total_pts, const int64_t* idx, int K, int compat_neg_index,
+                                     float* out, void* stream)
+{
+    if (B < 0 || K < 0 || total_pts < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || !params_ok(p))
+        return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4 || H >= (1 << 20)) return PCP_ERR_INVALID_ARG;
+    if (B == 0 || K == 0) return PCP_OK;
+    if (!depth || !rgb || !offsets || !idx || !out || (total_pts > 0 && !pix)) return PCP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k1_gather_pixels, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, depth, rgb,
+                       H * W, W, Hc, Wc, pcp_to_dev(p), pix, (const long long*)offsets, (long long)total_pts,
+                       (const long long*)idx, K, compat_neg_index, out);
     return pcp_launch_status();
 }
 

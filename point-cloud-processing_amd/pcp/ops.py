@@ -266,6 +266,23 @@ def gather_rgb(rgb, offsets, idx, compat_neg_index=True):
     return out
 
 
+def gather_rgb_pixels(depth, rgb, params, pix, offsets, idx, compat_neg_index=True, out=None):
+    """pc_rgb[idx] (DP3:48) evaluated from the sampled points' source pixels (pcp_gather_rgb_pixels): same values as
+    gather_rgb over stage 1's rgb32, without stage 1 ever producing rgb32."""
+    _require_cuda(depth, rgb, pix, offsets, idx)
+    _chk(depth, torch.float32, "depth"); _chk(rgb, torch.uint8, "rgb"); _chk(pix, torch.int32, "pix")
+    _chk(offsets, torch.int64, "offsets"); _chk(idx, torch.int64, "idx")
+    B, H, W = depth.shape
+    K = idx.shape[1]
+    if idx.shape[0] != B or offsets.numel() != B + 1:
+        raise ValueError("idx / offsets do not match the batch")
+    if out is None:
+        out = torch.empty((B, K, 3), dtype=torch.float32, device=depth.device)
+    _call(depth.device, load_library().pcp_gather_rgb_pixels, _ptr(depth), _ptr(rgb), B, H, W, rgb.shape[1], rgb.shape[2],
+          C.byref(params), _ptr(pix), _ptr(offsets), pix.shape[0], _ptr(idx), K, 1 if compat_neg_index else 0, _ptr(out))
+    return out
+
+
 def pack_dp3(xyz, rgb):
     _require_cuda(xyz, rgb)
     _chk(xyz, torch.float32, "xyz"); _chk(rgb, torch.float32, "rgb")
@@ -359,7 +376,8 @@ class FramePipeline:
     def __init__(self, B, H, W, K, params, device="cuda", dist_mode=0, algo=0, cap_per_frame=None):
         self.B, self.H, self.W, self.K, self.params = B, H, W, K, params
         cap = B * (cap_per_frame if cap_per_frame is not None else H * W)
-        self.stage1 = Stage1(B, H, W, device, cap=cap, want=("xyz32", "rgb32"))
+        # colours are fetched for the K sampled points only (gather_rgb_pixels): stage 1 writes xyz32 + the source pixel
+        self.stage1 = Stage1(B, H, W, device, cap=cap, want=("xyz32", "pix"))
         self.fps = Fps(B, cap, H * W, K, device, dist_mode, algo)
         self.rgb_out = torch.empty((B, K, 3), dtype=torch.float32, device=device)
 
@@ -369,9 +387,15 @@ class FramePipeline:
         # total_pts = the rows stage 1 could store: if its capacity overflowed, offsets hold the TRUE counts and the FPS
         # and gather kernels drop every cloud that reaches past `cap` (all -1 / zero rows, f.overflow set)
         f.enqueue(out["xyz32"], offsets, self.stage1.cap)
-        _call(f.device, load_library().pcp_gather_rgb, _ptr(out["rgb32"]), _ptr(offsets), self.stage1.cap,
-              _ptr(f.idx), f.B, f.K, 1, _ptr(self.rgb_out))
+        self.gather(depth, rgb)
         return f.xyz, self.rgb_out, f.idx, offsets
+
+    def gather(self, depth, rgb):
+        """pc_rgb[idx] (DP3:48) for the last run's picks → self.rgb_out."""
+        f, s1 = self.fps, self.stage1
+        _call(f.device, load_library().pcp_gather_rgb_pixels, _ptr(depth), _ptr(rgb), f.B, self.H, self.W,
+              rgb.shape[1], rgb.shape[2], C.byref(self.params), _ptr(s1.out["pix"]), _ptr(s1.offsets), s1.cap,
+              _ptr(f.idx), f.K, 1, _ptr(self.rgb_out))
 
     def check(self):
         """Synchronising: raise if the last run() lost rows (stage-1 capacity) or skipped a cloud (FPS bounds)."""

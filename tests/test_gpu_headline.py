@@ -46,7 +46,12 @@ def _check_episode(depth_h, rgb_h, dist_mode, m_range):
     assert (np.diff(srt, axis=1) > 0).all(), "a frame picked the same point twice"
     rows = torch.from_numpy(idx_h + off_h[:-1, None]).cuda().reshape(-1)
     np.testing.assert_array_equal(pipe.stage1.out["xyz32"].index_select(0, rows).reshape(B, K, 3).cpu().numpy(), xyz_h)
-    np.testing.assert_array_equal(pipe.stage1.out["rgb32"].index_select(0, rows).reshape(B, K, 3).cpu().numpy(), col_h)
+    # the pipeline fetches colours from the sampled points' source pixels; a stage-1 run that stores every colour
+    # (rgb32) and a plain row gather must give the same values
+    s1 = ops.Stage1(B, H, W, "cuda", cap=int(off_h[-1]), want=("rgb32",))
+    full, off2 = s1.run(depth, rgb, params)
+    assert torch.equal(off2, off)
+    np.testing.assert_array_equal(full["rgb32"].index_select(0, rows).reshape(B, K, 3).cpu().numpy(), col_h)
 
 
 @pytest.mark.parametrize("dist_mode", [1, 0])

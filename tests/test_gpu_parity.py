@@ -350,6 +350,28 @@ def test_gather_and_pack():
     np.testing.assert_array_equal(packed.reshape(-1, 6), R.dp3_rows(xyz.reshape(-1, 3), got.reshape(-1, 3)))
 
 
+def test_gather_from_source_pixels_equals_gather_of_stored_colours():
+    """pcp_gather_rgb_pixels (colour lookup for the K sampled points only) vs pcp_gather_rgb over stage 1's rgb32, with
+    a colour image of another resolution, -1 padding (numpy negative index → last row) and an empty cloud."""
+    g = load_npz("stage1_64x96_c40x60.npz")
+    p = _ffi.make_params(intr_dict(g["dintr"]), intr_dict(g["cintr"]), T=g["T"], ext=g["ext"], apply_crop=False)
+    H, W = g["depth"].shape
+    depth = np.stack([g["depth"], np.zeros_like(g["depth"]), g["depth"][::-1].copy()])
+    rgb = np.stack([g["rgb"], g["rgb"], g["rgb"][::-1].copy()])
+    s1 = ops.Stage1(3, H, W, DEV, want=("rgb32", "pix"))
+    out, off = s1.run(dev(depth), dev(rgb), p)
+    m = np.diff(off.cpu().numpy())
+    assert m[1] == 0 and m[0] > 100
+    rng = np.random.default_rng(33)
+    idx = np.stack([np.r_[rng.integers(0, max(mb, 1), 60), [-1, -1, -1, -1]] for mb in m]).astype(np.int64)
+    idx[1] = -1
+    for compat in (True, False):
+        a = ops.gather_rgb(out["rgb32"], off, dev(idx), compat).cpu().numpy()
+        b = ops.gather_rgb_pixels(dev(depth), dev(rgb), p, out["pix"], off, dev(idx), compat).cpu().numpy()
+        np.testing.assert_array_equal(a, b)
+    assert (b[1] == 0).all() and a[0].any()
+
+
 def test_frame_pipeline_vs_oracle_config1():
     """BASELINE.json configs[0]: one 640x480 frame → crop → 1024-pt FPS (plus 2 more seeds)."""
     intr = bench_intr()

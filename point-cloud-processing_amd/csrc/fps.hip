@@ -539,6 +539,18 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
                 if (aff) {
                     const unsigned np = pend >> 30;             // < PEND: a full list was flushed in its round
                     pend = (pend & 0x3fffffffu) | ((unsigned)k << (10u * np)) | ((np + 1u) << 30);
+                    // Tighten the bucket's upper bound without touching its rows: after this sample no point of the
+                    // bucket is farther from the sample set than the box's farthest corner is from the sample (same
+                    // rounded operation sequence as a point distance, and rounding is monotone, so the bound holds
+                    // in f32 too).  A pending bucket is not a candidate, so the high word of its key is free to
+                    // carry the bound; the flush rewrites the whole key.  Far fewer buckets then "could win" and have
+                    // to be streamed in the early rounds.  (A bucket holding a NaN point has an infinite box, see
+                    // the prologue: its bound never tightens, like that point's min-distance.)
+                    const float fx = fabsf(sx - blo[0]) >= fabsf(sx - bhi[0]) ? blo[0] : bhi[0];
+                    const float fy = fabsf(sy - blo[1]) >= fabsf(sy - bhi[1]) ? blo[1] : bhi[1];
+                    const float fz = fabsf(sz - blo[2]) >= fabsf(sz - bhi[2]) ? blo[2] : bhi[2];
+                    const float ub = fminf(cmax, dist2<MODE>(sx, sy, sz, fx, fy, fz));
+                    key = ((unsigned long long)__float_as_uint(ub) << 32) | (key & 0xffffffffull);
                 }
                 need_idle = (__ballot(aff) >> ((wmax_j / NW) & 63)) & 1ull;  // the wave's clean top is no longer clean
             }
@@ -763,6 +775,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         const int rn = min(BS, M - r0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { blo[s][c] = INFINITY; bhi[s][c] = -INFINITY; }
+        bool nan_pt = false;
         for (int i = 0; i < rn; i += 8) {
             float4 pt[8];
 #pragma unroll
@@ -772,7 +785,14 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
                 blo[s][0] = fminf(blo[s][0], pt[u].x); bhi[s][0] = fmaxf(bhi[s][0], pt[u].x);
                 blo[s][1] = fminf(blo[s][1], pt[u].y); bhi[s][1] = fmaxf(bhi[s][1], pt[u].y);
                 blo[s][2] = fminf(blo[s][2], pt[u].z); bhi[s][2] = fmaxf(bhi[s][2], pt[u].z);
+                nan_pt = nan_pt || !(pt[u].x == pt[u].x && pt[u].y == pt[u].y && pt[u].z == pt[u].z);
             }
+        }
+        // fminf / fmaxf skip NaN coordinates, so the box would not cover such a point; its distances are NaN and its
+        // min-distance never drops — give the bucket an infinite box so that no bound derived from the box ever does
+        if (nan_pt) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { blo[s][c] = -INFINITY; bhi[s][c] = INFINITY; }
         }
         key[s] = j < NB ? make_key(FLT_MAX, 0u) : 0ull;         // FLT_MAX: active in round 1; 0: never
     }

@@ -402,6 +402,9 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
         }
     }
 
+#if defined(PCP_FPS_STOP_AFTER) && PCP_FPS_STOP_AFTER == 1
+    return;
+#endif
 #ifdef PCP_FPS_STAMPS
     STAMP(q1);
 #endif
@@ -433,6 +436,9 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
         for (int j = 0; j < CPT; ++j) { cellcnt[tid * CPT + j] = ex; ex += local[j]; }
     }
     __syncthreads();
+#if defined(PCP_FPS_STOP_AFTER) && PCP_FPS_STOP_AFTER == 2
+    return;
+#endif
 #ifdef PCP_FPS_STAMPS
     STAMP(q2);
 #endif
@@ -757,6 +763,9 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     STAMP(tp0);
 #endif
     fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
+#if defined(PCP_FPS_STOP_AFTER) && PCP_FPS_STOP_AFTER <= 3
+    return;                                                      // tuning builds: time the prologue's phases
+#endif
 
     // ---- prologue 3: buckets and their owners ---------------------------------------------------------
     // 64-row chunks per bucket; the single-chunk shape is only launched for clouds of <= 64·NBMAX points

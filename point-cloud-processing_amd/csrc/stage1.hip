@@ -160,8 +160,8 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
 {
     __shared__ int wave_cnt[4];
     __shared__ double pk_cam[4][3][K1_PACK_MAX];                  // SoA: consecutive survivors 8 bytes apart, no bank conflicts
-    __shared__ unsigned char pk_pos[4][K1_PACK_MAX];
-    __shared__ unsigned long long pk_mask[4][4];
+    __shared__ int pk_pos[4][K1_PACK_MAX];                        // dword slots: byte-wide ones share banks four to a word
+    __shared__ unsigned char pk_res[4][256];                      // projection verdict per original pixel slot
     const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
     const int lane = pcp_lane(), wave = threadIdx.x >> 6;
     const float* dframe = depth + (size_t)b * HW;
@@ -222,27 +222,26 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
 
     unsigned long long keep[4];
     if (npre <= K1_PACK_MAX) {                                        // wave-uniform
-        if (lane < 4) pk_mask[wave][lane] = 0ull;
         int off = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if ((pre[r] >> lane) & 1ull) {
                 const int c = off + __popcll(pre[r] & lt);
                 pk_cam[wave][0][c] = cam[r][0]; pk_cam[wave][1][c] = cam[r][1]; pk_cam[wave][2][c] = cam[r][2];
-                pk_pos[wave][c] = (unsigned char)(r * 64 + lane);
+                pk_pos[wave][c] = r * 64 + lane;
             }
             off += __popcll(pre[r]);
         }
         for (int c = lane; c < npre; c += 64) {                       // one wave: LDS accesses stay in program order
             const double cc[3] = {pk_cam[wave][0][c], pk_cam[wave][1][c], pk_cam[wave][2][c]};
             float col[3];
-            if (align_math<false>(P, cc, img, Hc, Wc, col)) {
-                const int p = pk_pos[wave][c];
-                atomicOr(&pk_mask[wave][p >> 6], 1ull << (p & 63));
-            }
+            // the verdict goes back to the pixel's own slot with a plain byte store (an atomicOr into four mask words
+            // serialised the whole wave on one address: 34 % of this kernel's LDS cycles were bank conflicts)
+            pk_res[wave][pk_pos[wave][c]] = (unsigned char)align_math<false>(P, cc, img, Hc, Wc, col);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) keep[r] = pk_mask[wave][r];
+        for (int r = 0; r < 4; ++r)                                   // slots that did not pass the pre-test were never written: masked by pre
+            keep[r] = __ballot(((pre[r] >> lane) & 1ull) && pk_res[wave][r * 64 + lane]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

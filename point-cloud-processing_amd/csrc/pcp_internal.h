@@ -13,6 +13,7 @@
 // Device-side copy of pcp_params, passed by value as a kernel argument.
 struct DevParams {
     double dfx, dfy, dcx, dcy;      // depth intrinsics
+    double rdfx, rdfy;              // RN(1/dfx), RN(1/dfy) for pcp_quot(); 0 = this launch divides the plain way
     double cfx, cfy, ccx, ccy;      // colour intrinsics
     double T[12];                   // rows 0..2 of the depth->colour 4x4
     double E[12];                   // rows 0..2 of the base<-camera 4x4
@@ -22,10 +23,21 @@ struct DevParams {
     int apply_crop, transform_fma;
 };
 
+// Correctly rounded reciprocal of a launch-constant divisor (IEEE division on the host), or 0 when the divisor is
+// not a plain mid-range number — the kernels then use true divisions throughout.
+static inline double pcp_safe_recip(double d)
+{
+    const double a = d < 0 ? -d : d;
+    if (!(a > 0x1p-200 && a < 0x1p200)) return 0.0;
+    return 1.0 / d;
+}
+
 static inline DevParams pcp_to_dev(const pcp_params* p)
 {
     DevParams d;
     d.dfx = p->depth.fx; d.dfy = p->depth.fy; d.dcx = p->depth.cx; d.dcy = p->depth.cy;
+    d.rdfx = pcp_safe_recip(d.dfx); d.rdfy = pcp_safe_recip(d.dfy);
+    if (d.rdfx == 0.0 || d.rdfy == 0.0) d.rdfx = d.rdfy = 0.0;
     d.cfx = p->color.fx; d.cfy = p->color.fy; d.ccx = p->color.cx; d.ccy = p->color.cy;
     for (int i = 0; i < 12; ++i) { d.T[i] = p->T_d2c[i]; d.E[i] = p->ext[i]; }
     for (int i = 0; i < 3; ++i) { d.lo[i] = p->ws_lo[i]; d.hi[i] = p->ws_hi[i]; }
@@ -47,6 +59,29 @@ static inline int pcp_launch_status()
 }
 
 static inline size_t pcp_align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// ---- exact FP64 division by a launch constant ------------------------------------------------------
+// n / d, correctly rounded — bit for bit the IEEE division the reference's numpy expression performs — given
+// r = RN(1/d), d a mid-range number (pcp_safe_recip).  q0 = RN(n*r) is within a few ulp; one residual step
+// (e = n - q*d is exact in an FMA) makes q1 a faithful quotient, and a second one is Markstein's final step: with r
+// the correctly rounded reciprocal and q1 faithful, RN(q1 + r*(n - q1*d)) = RN(n/d) provided nothing over- or
+// underflows on the way.  That proviso is checked on the result's exponent: a quotient outside a generous safe range
+// (infinities and NaN included) sets `bad`, and the caller recomputes with true divisions — one wave-uniform,
+// practically never taken branch per wave instead of one per quotient.  A zero numerator keeps q0, which carries the
+// sign n/d would have.  The FP64 division sequence (v_div_scale x2, v_rcp_f64, Newton steps, v_div_fmas, v_div_fixup)
+// costs about three times as many issue cycles.
+__device__ __forceinline__ double pcp_quot(double n, double d, double r, bool& bad)
+{
+    const double q0 = n * r;
+    double e = fma(-q0, d, n);
+    const double q1 = fma(e, r, q0);
+    e = fma(-q1, d, n);
+    const double q = fma(e, r, q1);
+    const unsigned ex = ((unsigned)__double2hiint(q) >> 20) & 0x7ffu;      // biased exponent
+    const bool zero = n == 0.0;
+    bad = bad || !(ex - 523u < 1000u || zero);                            // 2^-500 <= |q| < 2^500, or an exact zero
+    return zero ? q0 : q;
+}
 
 // ---- wave / block primitives (64-wide wavefronts) ---------------------------------------
 

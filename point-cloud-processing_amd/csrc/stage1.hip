@@ -179,7 +179,9 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
     const int dv64 = 64 / W, du64 = 64 - dv64 * W;                    // 64 = dv64*W + du64 (scalar)
     // Phase by phase over the wave's four rounds instead of pixel by pixel: each phase needs only a few of the ~40
     // FP64 parameters, so they stay in scalar registers instead of being re-fetched for every round.
-    bool ok[4];
+    bool ok[4], bad = false;
+    float dep[4];
+    int ppu[4], ppv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                                     // deproject, XPC:58-64
         const int i = tile * PCP_TILE + (wave * 4 + r) * 64 + lane;
@@ -189,10 +191,19 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
         }
         const float d = i < HW ? dframe[i] : 0.0f;                    // 0 fails the range test below
         const double z = (double)d;
-        cam[r][0] = (((double)pu - P.dcx) * z) / P.dfx;                // XPC:62
-        cam[r][1] = (((double)pv - P.dcy) * z) / P.dfy;                // XPC:63
+        dep[r] = d; ppu[r] = pu; ppv[r] = pv;
+        cam[r][0] = pcp_quot(((double)pu - P.dcx) * z, P.dfx, P.rdfx, bad);     // XPC:62, exact (see pcp_quot)
+        cam[r][1] = pcp_quot(((double)pv - P.dcy) * z, P.dfy, P.rdfy, bad);     // XPC:63
         cam[r][2] = z;
         ok[r] = (i < HW) & (d > P.z_min) & (d < P.z_max);             // XPC:109 (f32 compares)
+    }
+    if (__any(bad) || P.rdfx == 0.0) {                                // wave-uniform: non-finite / extreme values, odd fx
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double z = (double)dep[r];
+            cam[r][0] = (((double)ppu[r] - P.dcx) * z) / P.dfx;
+            cam[r][1] = (((double)ppv[r] - P.dcy) * z) / P.dfy;
+        }
     }
     if (CROP) {
 #pragma unroll
@@ -378,9 +389,14 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
         pcp_divmod(i, W, invW, &pv, &pu);
         const double z = (double)dframe[i];
         double cam[3];
-        cam[0] = (((double)pu - P.dcx) * z) / P.dfx;                  // XPC:62 multiply, then divide
-        cam[1] = (((double)pv - P.dcy) * z) / P.dfy;                  // XPC:63
+        bool bad = false;
+        cam[0] = pcp_quot(((double)pu - P.dcx) * z, P.dfx, P.rdfx, bad);        // XPC:62 multiply, then divide (exact)
+        cam[1] = pcp_quot(((double)pv - P.dcy) * z, P.dfy, P.rdfy, bad);        // XPC:63
         cam[2] = z;
+        if (__any(bad) || P.rdfx == 0.0) {                            // practically never: extreme values, odd fx
+            cam[0] = (((double)pu - P.dcx) * z) / P.dfx;
+            cam[1] = (((double)pv - P.dcy) * z) / P.dfy;
+        }
         if (xyz_cam64) { xyz_cam64[3 * row] = cam[0]; xyz_cam64[3 * row + 1] = cam[1]; xyz_cam64[3 * row + 2] = cam[2]; }
         if (xyz64 || xyz32) {
             double g[3];

@@ -15,7 +15,7 @@ ks = glob.glob(os.path.join(out, "trace", "**", "*_kernel_stats.csv"), recursive
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 
-OURS = ("fps_", "k1_", "pcp_", "crop_", "gather", "pack")
+OURS = ("fps_", "k1_", "pcp_", "crop_", "gather", "pack", "sor_", "vox_", "rocprim")
 acc = defaultdict(lambda: defaultdict(list))
 for sub in ("fetch", "write", "sq"):
     for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):

@@ -78,10 +78,16 @@ template <int KCAP>
 __global__ void __launch_bounds__(256, 1)
 sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
         const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
-        int nb, const unsigned long long* __restrict__ minb, double* __restrict__ avg)
+        int nb, const unsigned long long* __restrict__ minb, double* __restrict__ avg,
+        const unsigned int* __restrict__ todo, const unsigned int* __restrict__ todo_cnt)
 {
     __shared__ double queue[SOR_Q * 256];
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // with a to-do list (the points sor_knn_coop could not finish) thread t serves todo[t]; without, sorted point t
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (todo) {
+        if (j >= (long long)*todo_cnt) return;
+        j = todo[j];
+    }
     if (j >= offsets[B]) return;
     const unsigned long long key = keys[j];
     const int b = (int)(key >> 48);
@@ -162,6 +168,251 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
     for (int t = 0; t < KCAP; ++t)
         if (t < k) s += sqrt(best[t]);
     avg[vals[j]] = s / (double)k;
+}
+
+
+// ---- wave-cooperative k-NN (first ring) --------------------------------------------------------------------
+// One wave serves 64 consecutive SORTED points.  Consecutive sorted points share their (x,y) grid row and walk it in
+// z, so their 27-cell neighbourhoods overlap almost completely: the union over a row group is nine contiguous key
+// runs (rows x-1..x+1, y-1..y+1, cells zmin-1..zmax+1).  The wave finds the nine runs with eighteen binary searches
+// done side by side by eighteen lanes, stages the runs' points in LDS with coalesced loads, and every lane scans
+// the staged candidates with LDS broadcast reads — no per-lane global gathers, no per-lane binary searches, no
+// divergent row loops.  Candidates that beat a lane's bound go to its LDS queue and the queues are drained in
+// lockstep into a sorted top-k kept in registers (one compare per slot).  Scanning a superset of a lane's own 27
+// cells cannot change its result: the k smallest distances are a multiset and the ring proof below only needs the 27
+// cells to be covered.  A lane whose k-th distance is not provably inside the first ring (or whose cloud has no more
+// than k points) is appended to a to-do list that sor_knn finishes with its wider search.
+#ifndef SORC_CAND
+#define SORC_CAND 256          // candidates staged per wave and chunk (FP64 x,y,z: 6 KB)
+#endif
+#define SORC_BATCH 8           // candidates scanned between two queue checks
+#define SORC_QCAP 32           // queue slots per lane (a drain is forced while more than QCAP - BATCH are used): deep
+                               // queues keep the lockstep drains rare and well filled — with 16 slots a wave ran ~220
+                               // insertion passes for ~40 queued candidates per lane, most of them for a handful of lanes.
+                               // A slot holds the candidate's 16-bit position in the staged chunk, not its distance
+                               // (recomputed exactly at the drain)
+#ifndef SORC_WAVES
+#define SORC_WAVES 2           // waves per workgroup (20 KB of LDS: seven workgroups = fourteen waves per CU)
+#endif
+
+template <int KCAP>
+__device__ __forceinline__ void sor_insert1(double (&best)[KCAP], double d)
+{
+    bool c[KCAP];
+#pragma unroll
+    for (int t = 0; t < KCAP; ++t) c[t] = best[t] > d;                // ascending array: true from the insert position on
+#pragma unroll
+    for (int t = KCAP - 1; t > 0; --t) best[t] = c[t - 1] ? best[t - 1] : (c[t] ? d : best[t]);
+    best[0] = c[0] ? d : best[0];
+}
+
+__device__ __forceinline__ long long sor_rl64(long long v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, lane);
+    const int hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int KCAP>
+__global__ void __launch_bounds__(64 * SORC_WAVES)
+sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
+             const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
+             int nb, double* __restrict__ avg, unsigned int* __restrict__ todo, unsigned int* __restrict__ todo_cnt)
+{
+    // The scan runs in FLOAT (candidate coordinates rounded on the fly) and only FILTERS: a candidate whose float
+    // distance is within a rigorous error margin of the lane's bound is queued (its 16-bit position in the staged chunk),
+    // everything else is provably farther than the bound.  The drain reads the queued candidates' FP64 coordinates
+    // back from LDS (a per-lane gather), computes the exact distance the way the oracle does and inserts it into the
+    // sorted top-k — every value that decides anything is exact, and the per-candidate cost is three conversions and
+    // six FP32 operations instead of eight FP64 ones.  (Gathering the exact coordinates from global memory instead
+    // made the kernel texture-address bound: 64 lanes x 3 loads, each its own cache line, per queued candidate.)
+    __shared__ double cand_s[SORC_WAVES][3][SORC_CAND];
+    __shared__ unsigned short queue_s[SORC_WAVES][SORC_QCAP + 1][64];     // last row: dump slot of the branch-free push
+    const int lane = pcp_lane(), wave = threadIdx.x >> 6;
+    const long long n = offsets[B];
+    const long long j0 = ((long long)blockIdx.x * SORC_WAVES + wave) * 64;
+    if (j0 >= n) return;                                              // wave-uniform
+    const long long j = j0 + lane;
+    const bool have = j < n;
+    const long long jj = have ? j : n - 1;
+    const unsigned long long key = keys[jj];
+    const int b = (int)(key >> 48);
+    const int cz = (int)(key & 0xFFFF);
+    const long long lo = offsets[b], hi = offsets[b + 1];
+    const long long M = hi - lo;
+    const int k = (long long)nb < M ? nb : (int)M;
+    const double px = sxyz[3 * jj], py = sxyz[3 * jj + 1], pz = sxyz[3 * jj + 2];
+    double (*cand)[SORC_CAND] = cand_s[wave];
+    unsigned short (*queue)[64] = queue_s[wave];
+    double best[KCAP];
+#pragma unroll
+    for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
+    // Only a k-th distance inside the first ring can be proven here (every point closer than `lim` is scanned), so a
+    // candidate at or beyond lim^2 is of no use: the bound starts there instead of at infinity.  The early, far
+    // candidates are then never queued or inserted (about 44 candidates per lane lie inside the ring at the density
+    // sor_cell_size aims for, against ~700 scanned), and a lane that ends with fewer than k of them goes to the to-do list.
+    const double lim = cell * (1.0 - 1e-9);
+    const double lim2 = lim * lim;
+    double tau = lim2;
+    int qn = 0;
+#ifdef SORC_STATS
+    int st_drain = 0, st_ins = 0, st_push = 0, st_grp = 0, st_cand = 0;
+    unsigned long long tm_search = 0, tm_stage = 0, tm_scan = 0, tm_drain = 0, tm0 = __builtin_amdgcn_s_memtime(), tmx;
+#define SORC_T(acc) do { tmx = __builtin_amdgcn_s_memtime(); acc += tmx - tm0; tm0 = tmx; } while (0)
+#else
+#define SORC_T(acc) do { } while (0)
+#endif
+    const bool use = have && M > k;
+    unsigned long long rem = __ballot(use);
+    while (rem) {                                                     // one trip per (cloud, x, y) row present in the wave
+        const int leader = __ffsll((long long)rem) - 1;
+        const unsigned long long rowkey = (unsigned long long)sor_rl64((long long)(key >> 16), leader);
+        const unsigned long long grp = __ballot(use && (key >> 16) == rowkey);
+        rem &= ~grp;
+        const bool act = (grp >> lane) & 1ull;
+        // the group's lanes are consecutive sorted points of one row: z ascends from its first to its last lane
+        const int zfirst = __builtin_amdgcn_readlane(cz, __ffsll((long long)grp) - 1);
+        const int zlast = __builtin_amdgcn_readlane(cz, 63 - __clzll((long long)grp));
+        const int zA = zfirst > 0 ? zfirst - 1 : 0, zB = zlast < 65535 ? zlast + 1 : 65535;
+        const int gx = (int)((rowkey >> 16) & 0xFFFF), gy = (int)(rowkey & 0xFFFF);
+        const unsigned long long cloud = (rowkey >> 32) << 48;
+        const long long glo = sor_rl64(lo, leader), ghi = sor_rl64(hi, leader);
+        // eighteen searches side by side: lane s < 9 finds where row s begins at cell zA, lane 9 + s where it ends at zB
+        long long pos = glo;
+        {
+            // rows in the order they are scanned: the group's own row first, then the four that share a face with it,
+            // then the four diagonal ones — near candidates first, so the lanes' bounds tighten early
+            const int s = lane < 9 ? lane : lane - 9;
+            const int ddx = (0x28215 >> (2 * s)) & 3, ddy = (0x22161 >> (2 * s)) & 3;   // packed {1,1,1,0,2,0,0,2,2} / {1,0,2,1,1,0,2,0,2}
+            const int x = gx + ddx - 1, y = gy + ddy - 1;
+            if (lane < 18 && x >= 0 && x <= 65535 && y >= 0 && y <= 65535) {
+                const unsigned long long row = cloud | ((unsigned long long)x << 32) | ((unsigned long long)y << 16);
+                long long a = glo, e = ghi;
+                if (lane < 9) {                                       // first key >= row|zA
+                    const unsigned long long t = row | (unsigned long long)zA;
+                    while (a < e) { const long long mid = (a + e) >> 1; if (keys[mid] < t) a = mid + 1; else e = mid; }
+                } else {                                              // first key > row|zB
+                    const unsigned long long t = row | (unsigned long long)zB;
+                    while (a < e) { const long long mid = (a + e) >> 1; if (keys[mid] <= t) a = mid + 1; else e = mid; }
+                }
+                pos = a;
+            }
+        }
+        long long seg0[9];
+        int pre[10];
+        pre[0] = 0;
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            seg0[s] = sor_rl64(pos, s);
+            const long long e = sor_rl64(pos, 9 + s);
+            pre[s + 1] = pre[s] + (int)(e > seg0[s] ? e - seg0[s] : 0);
+        }
+        const int N = pre[9];
+#ifdef SORC_STATS
+        ++st_grp; st_cand += N;
+        SORC_T(tm_search);
+#endif
+        auto sorted_pos = [&](int ord) -> long long {                 // position in the sorted arrays of the group's ord-th candidate
+            long long g = seg0[0] + ord;
+#pragma unroll
+            for (int t = 1; t < 9; ++t) g = ord >= pre[t] ? seg0[t] + (ord - pre[t]) : g;
+            return g;
+        };
+        // float error margin: a coordinate c and its float differ by <= 2^-24 |c|, every coordinate here is within
+        // Rmax of the group's first point o, so a component difference is off by <= 2^-23 (|o| + Rmax) plus its own
+        // rounding; with sqrt(tau) <= cell <= Rmax the margin below covers the three components and the float products
+        // and sums several times over.  Far-away clouds (|o| >> cell) make the filter pass everything: slower, never wrong.
+        const int first_lane = __ffsll((long long)grp) - 1;
+        const double omag = fabs(__longlong_as_double(sor_rl64(__double_as_longlong(px), first_lane))) +
+                            fabs(__longlong_as_double(sor_rl64(__double_as_longlong(py), first_lane))) +
+                            fabs(__longlong_as_double(sor_rl64(__double_as_longlong(pz), first_lane)));
+        const float qx = (float)px, qy = (float)py, qz = (float)pz;
+        const double Rmax = (double)(zB - zA + 4) * cell;             // cells zA..zB in z, three cells in x and y, plus slack
+        const double emargin = 0x1p-20 * (omag + 2.0 * Rmax);
+        auto float_bound = [&](double t) -> float {
+            const double r = sqrt(t) + emargin;
+            return (float)(r * r * (1.0 + 0x1p-18));
+        };
+        float tau32 = float_bound(tau);
+        auto drain = [&]() {                                          // must run before the staged chunk is replaced
+#ifdef SORC_STATS
+            ++st_drain;
+            SORC_T(tm_scan);
+#endif
+            for (int s0 = 0; s0 < SORC_QCAP; s0 += 4) {
+                if (!__any(s0 < qn)) break;                           // wave-uniform: queues fill from slot 0 up
+                double d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                         // four exact distances in flight
+                    const bool live = s0 + u < qn;
+                    const int c = live ? (int)queue[s0 + u][lane] : 0;            // position in the staged chunk
+                    const double dx = px - cand[0][c], dy = py - cand[1][c], dz = pz - cand[2][c];
+                    d[u] = live ? ((dx * dx) + (dy * dy)) + (dz * dz) : DBL_MAX;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (__any(d[u] < tau)) {                          // float-margin false positives and stale entries stop here
+#ifdef SORC_STATS
+                        ++st_ins;
+#endif
+                        sor_insert1<KCAP>(best, d[u] < tau ? d[u] : DBL_MAX);
+                    }
+            }
+            qn = 0;
+            tau = fmin(lim2, sor_kth<KCAP>(best, k));
+            tau32 = float_bound(tau);
+            SORC_T(tm_drain);
+        };
+        for (int cb = 0; cb < N; cb += SORC_CAND) {
+            const int cn = N - cb < SORC_CAND ? N - cb : SORC_CAND;
+            for (int i = lane; i < cn; i += 64) {                     // stage: consecutive lanes read consecutive sorted points
+                const long long g = sorted_pos(cb + i);
+                cand[0][i] = sxyz[3 * g]; cand[1][i] = sxyz[3 * g + 1]; cand[2][i] = sxyz[3 * g + 2];
+            }
+            SORC_T(tm_stage);
+            for (int c0 = 0; c0 < cn; c0 += SORC_BATCH) {
+                if (__any(qn > SORC_QCAP - SORC_BATCH)) drain();
+                float d[SORC_BATCH];
+#pragma unroll
+                for (int u = 0; u < SORC_BATCH; ++u) {                // all LDS broadcast reads of the batch in flight together
+                    const int c = c0 + u < cn ? c0 + u : cn - 1;      // a repeated last candidate is filtered below
+                    const float dx = qx - (float)cand[0][c], dy = qy - (float)cand[1][c], dz = qz - (float)cand[2][c];
+                    d[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                }
+#pragma unroll
+                for (int u = 0; u < SORC_BATCH; ++u) {                // branch-free push: losers write the dump row
+                    const bool win = act && c0 + u < cn && d[u] <= tau32;
+                    queue[win ? qn : SORC_QCAP][lane] = (unsigned short)(c0 + u);
+                    qn += win ? 1 : 0;
+#ifdef SORC_STATS
+                    st_push += win ? 1 : 0;
+#endif
+                }
+            }
+            drain();                                                  // queued positions refer to this chunk
+        }
+    }
+    const bool done = use && sor_kth<KCAP>(best, k) < lim2;           // k real entries, all inside the first ring
+#ifdef SORC_STATS
+    {
+        int pmax = st_push, psum = st_push;
+        for (int dd = 32; dd >= 1; dd >>= 1) { pmax = max(pmax, __shfl_xor(pmax, dd, 64)); psum += __shfl_xor(psum, dd, 64); }
+        const int nd = (int)__popcll(__ballot(done));
+        if (blockIdx.x % 8000 == 17 && wave == 1 && lane == 0)
+            printf("[sorc] blk %d groups %d cand %d drains %d inserts %d push max %d avg %.1f done %d | cycles search %llu stage %llu scan %llu drain %llu\n", blockIdx.x, st_grp, st_cand, st_drain, st_ins, pmax, psum / 64.0, nd, tm_search, tm_stage, tm_scan, tm_drain);
+    }
+#endif
+    if (have) {
+        if (done) {
+            double sum = 0.0;
+#pragma unroll
+            for (int t = 0; t < KCAP; ++t)
+                if (t < k) sum += sqrt(best[t]);
+            avg[vals[j]] = sum / (double)k;
+        } else {
+            todo[atomicAdd(todo_cnt, 1u)] = (unsigned int)j;
+        }
+    }
 }
 
 // One wave per cloud: strictly sequential sums (point order), as std::accumulate does.  The lanes load 64
@@ -268,7 +519,7 @@ sor_scatter(const double* __restrict__ xyz, const float* __restrict__ rgb, const
     }
 }
 
-struct SorLayout { VoxLayout v; size_t sxyz, avg, stats, end; };
+struct SorLayout { VoxLayout v; size_t sxyz, avg, stats, todo, todo_cnt, end; };
 
 static SorLayout sor_layout(int B, int64_t cap)
 {
@@ -279,6 +530,8 @@ static SorLayout sor_layout(int B, int64_t cap)
     L.sxyz = o;  o += pcp_align256(n * 24);
     L.avg = o;   o += pcp_align256(n * 8);
     L.stats = o; o += pcp_align256((size_t)(B > 0 ? B : 1) * 32);
+    L.todo = o;  o += pcp_align256(n * 4);
+    L.todo_cnt = o; o += 256;
     L.end = o;
     return L;
 }
@@ -334,16 +587,24 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
                                           keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
                                           64u, st));
     hipLaunchKernelGGL(sor_gather_sorted, dim3(nblk), dim3(256), 0, st, xyz, vals_out, off, B, sxyz);
-    if (nb_neighbors <= 8)
-        hipLaunchKernelGGL(sor_knn<8>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
-    else if (nb_neighbors <= 16)
-        hipLaunchKernelGGL(sor_knn<16>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
-    else if (nb_neighbors <= 20)
-        hipLaunchKernelGGL(sor_knn<20>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
-    else if (nb_neighbors <= 24)
-        hipLaunchKernelGGL(sor_knn<24>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
-    else
-        hipLaunchKernelGGL(sor_knn<32>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size, nb_neighbors, minb, avg);
+    unsigned int* todo = (unsigned int*)(w + L.todo);
+    unsigned int* todo_cnt = (unsigned int*)(w + L.todo_cnt);
+    PCP_HIP_TRY(hipMemsetAsync(todo_cnt, 0, sizeof(unsigned int), st));
+    // first ring cooperatively (one wave per 64 sorted points); whatever it cannot prove goes through the per-point search
+#define PCP_SOR_LAUNCH(KC)                                                                                              \
+    do {                                                                                                                \
+        hipLaunchKernelGGL(sor_knn_coop<KC>, dim3((unsigned)((cap_pts + 64 * SORC_WAVES - 1) / (64 * SORC_WAVES))),      \
+                           dim3(64 * SORC_WAVES), 0, st, sxyz, keys_out, vals_out, off, B, cell_size,                    \
+                           nb_neighbors, avg, todo, todo_cnt);                                                          \
+        hipLaunchKernelGGL(sor_knn<KC>, dim3(nblk), dim3(256), 0, st, sxyz, keys_out, vals_out, off, B, cell_size,       \
+                           nb_neighbors, minb, avg, (const unsigned int*)todo, (const unsigned int*)todo_cnt);          \
+    } while (0)
+    if (nb_neighbors <= 8) PCP_SOR_LAUNCH(8);
+    else if (nb_neighbors <= 16) PCP_SOR_LAUNCH(16);
+    else if (nb_neighbors <= 20) PCP_SOR_LAUNCH(20);
+    else if (nb_neighbors <= 24) PCP_SOR_LAUNCH(24);
+    else PCP_SOR_LAUNCH(32);
+#undef PCP_SOR_LAUNCH
     hipLaunchKernelGGL(sor_stats, dim3(B), dim3(64), 0, st, avg, off, std_ratio, stats);
     hipLaunchKernelGGL(sor_flags, dim3(tiles), dim3(256), 0, st, avg, off, B, stats, masks, tile_cnt);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);

@@ -74,6 +74,9 @@ __device__ __forceinline__ long long sor_lower_bound(const unsigned long long* _
 // lockstep and the insertion code runs with most lanes doing useful work.
 #define SOR_Q 8
 
+#ifdef SOR_DBG
+__device__ unsigned int sor_dbg[8];
+#endif
 template <int KCAP>
 __global__ void __launch_bounds__(256, 1)
 sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
@@ -123,8 +126,12 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
         if (__any(qn == SOR_Q)) drain();
     };
     bool done = false;
+#ifdef SOR_DBG
+    int r_done = 0;
+#endif
     if (M > k) {
-        for (int r = SOR_RSTART; r <= SOR_RMAX && !done; ++r) {
+        // a to-do point comes from sor_knn_coop, which has scanned its first ring already and found it too small
+        for (int r = todo ? 2 : SOR_RSTART; r <= SOR_RMAX && !done; ++r) {
             reset();
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > 65535 ? 65535 : cz + r;
             // rows nearest the query's own row first (offsets 0,-1,+1,-2,+2,...): the bound tightens early and
@@ -153,8 +160,14 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
             drain();
             const double lim = ((double)r * cell) * (1.0 - 1e-9);      // every point closer than this was scanned
             done = tau <= lim * lim;
+#ifdef SOR_DBG
+            if (done) r_done = r;
+#endif
         }
     }
+#ifdef SOR_DBG
+    if (todo) atomicAdd(&sor_dbg[r_done], 1u);
+#endif
     if (!done) {                                                     // isolated point or tiny cloud: whole cloud
         reset();
         for (long long t = lo; t < hi; ++t) {
@@ -402,55 +415,88 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
             printf("[sorc] blk %d groups %d cand %d drains %d inserts %d push max %d avg %.1f done %d | cycles search %llu stage %llu scan %llu drain %llu\n", blockIdx.x, st_grp, st_cand, st_drain, st_ins, pmax, psum / 64.0, nd, tm_search, tm_stage, tm_scan, tm_drain);
     }
 #endif
-    if (have) {
-        if (done) {
-            double sum = 0.0;
+    if (have && done) {
+        double sum = 0.0;
 #pragma unroll
-            for (int t = 0; t < KCAP; ++t)
-                if (t < k) sum += sqrt(best[t]);
-            avg[vals[j]] = sum / (double)k;
-        } else {
-            todo[atomicAdd(todo_cnt, 1u)] = (unsigned int)j;
-        }
+        for (int t = 0; t < KCAP; ++t)
+            if (t < k) sum += sqrt(best[t]);
+        avg[vals[j]] = sum / (double)k;
+    }
+    // one append per wave: the wave's unfinished points take consecutive to-do slots, so the lanes of the per-point
+    // search work on spatial neighbours (similar rows, similar trip counts)
+    const unsigned long long left = __ballot(have && !done);
+    if (left) {
+        unsigned int slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(todo_cnt, (unsigned int)__popcll(left));
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        if (have && !done) todo[slot0 + (unsigned int)__popcll(left & ((1ull << lane) - 1ull))] = (unsigned int)j;
     }
 }
 
-// One wave per cloud: strictly sequential sums (point order), as std::accumulate does.  The lanes load 64
-// values at a time and turn them into the addends in parallel (0.0 for a skipped value: adding +0.0 to
-// a non-negative running sum is exact); the addends go through LDS so that every lane holds all 64 of them
-// in registers (broadcast reads, issued ahead of the chain) and the serial part is 64 back-to-back
-// v_add_f64.   stats[b] = {mean, std, threshold, 0}
-__global__ void __launch_bounds__(64)
+// One workgroup per cloud: strictly sequential sums (point order), as std::accumulate does.  All four waves turn a
+// block of SOR_ST_BLOCK values into the addends in parallel (0.0 for a skipped value and for the padding of the last
+// group: adding +0.0 to a non-negative running sum is exact) and park them in LDS; wave 0 then runs the serial chain
+// over the block — broadcast LDS reads of the NEXT 32 addends are issued ahead of the 32 dependent v_add_f64 of the
+// current group, so the chain's own latency is all that is left.   stats[b] = {mean, std, threshold, 0}
+#define SOR_ST_BLOCK 8192
+#define SOR_ST_GROUP 32
+__global__ void __launch_bounds__(256)
 sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets, double std_ratio,
           double* __restrict__ stats)
 {
-    __shared__ double term_s[64];
-    const int b = blockIdx.x, lane = pcp_lane();
+    __shared__ double term_s[SOR_ST_BLOCK + 2 * SOR_ST_GROUP];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const long long lo = offsets[b], hi = offsets[b + 1];
     const long long M = hi - lo;
     double res[2] = {0.0, 0.0};
     double mean = 0.0;
     for (int pass = 0; pass < 2; ++pass) {
         double acc = 0.0;
-        double nxt = lo + lane < hi ? avg[lo + lane] : 0.0;
-        for (long long base = lo; base < hi; base += 64) {
-            const double y = nxt;
-            const long long ni = base + 64 + lane;
-            nxt = ni < hi ? avg[ni] : 0.0;                            // prefetch under the serial chain
-            double term;
-            if (pass == 0) term = y > 0.0 ? y : 0.0;
-            else term = y > 0.0 ? (y - mean) * (y - mean) : 0.0;
-            term_s[lane] = term;                                      // one wave: LDS accesses stay in program order
-            double op[64];
+        for (long long base = lo; base < hi; base += SOR_ST_BLOCK) {
+            const int n = (int)((hi - base) < SOR_ST_BLOCK ? (hi - base) : SOR_ST_BLOCK);
+            const int npad = (n + 2 * SOR_ST_GROUP - 1) / (2 * SOR_ST_GROUP) * (2 * SOR_ST_GROUP);
+            __syncthreads();                                          // the previous block's chain is through
+#pragma unroll 8
+            for (int i = tid; i < npad; i += 256) {
+                const double y = i < n ? avg[base + i] : 0.0;
+                double term;
+                if (pass == 0) term = y > 0.0 ? y : 0.0;
+                else term = y > 0.0 ? (y - mean) * (y - mean) : 0.0;
+                term_s[i] = term;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // two register groups, A and B: the reads of one are in flight under the other's chain.  The
+                // sched_barriers keep hipcc from sinking the reads down to their first use.
+                double ga[SOR_ST_GROUP], gb[SOR_ST_GROUP];
 #pragma unroll
-            for (int t = 0; t < 64; ++t) op[t] = term_s[t];
+                for (int t = 0; t < SOR_ST_GROUP; ++t) ga[t] = term_s[t];
+                for (int g = 0; g < npad; g += 2 * SOR_ST_GROUP) {
 #pragma unroll
-            for (int t = 0; t < 64; ++t) acc = acc + op[t];
+                    for (int t = 0; t < SOR_ST_GROUP; ++t) gb[t] = term_s[g + SOR_ST_GROUP + t];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < SOR_ST_GROUP; ++t) acc = acc + ga[t];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < SOR_ST_GROUP; ++t) ga[t] = term_s[g + 2 * SOR_ST_GROUP + t];   // last trip: pad rows
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < SOR_ST_GROUP; ++t) acc = acc + gb[t];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-        res[pass] = acc;
-        if (pass == 0) mean = acc / (double)M;
+        res[pass] = acc;                                              // wave 0 only; the other waves' copies are unused
+        if (pass == 0) {
+            // every wave needs the mean for its share of the second pass' addends
+            __syncthreads();
+            if (tid == 0) term_s[0] = acc / (double)M;
+            __syncthreads();
+            mean = term_s[0];
+        }
     }
-    if (lane == 0) {
+    if (tid == 0) {
         const double sd = sqrt(res[1] / (double)(M - 1));
         stats[4 * b] = mean; stats[4 * b + 1] = sd; stats[4 * b + 2] = mean + std_ratio * sd; stats[4 * b + 3] = 0.0;
     }
@@ -585,7 +631,7 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
     size_t temp_bytes = L.v.temp_bytes;
     PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.v.temp), temp_bytes, (const unsigned long long*)keys_in,
                                           keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
-                                          64u, st));
+                                          vox_sort_end_bit(B), st));
     hipLaunchKernelGGL(sor_gather_sorted, dim3(nblk), dim3(256), 0, st, xyz, vals_out, off, B, sxyz);
     unsigned int* todo = (unsigned int*)(w + L.todo);
     unsigned int* todo_cnt = (unsigned int*)(w + L.todo_cnt);
@@ -605,7 +651,17 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
     else if (nb_neighbors <= 24) PCP_SOR_LAUNCH(24);
     else PCP_SOR_LAUNCH(32);
 #undef PCP_SOR_LAUNCH
-    hipLaunchKernelGGL(sor_stats, dim3(B), dim3(64), 0, st, avg, off, std_ratio, stats);
+#ifdef SOR_DBG
+    {
+        unsigned int h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(sor_dbg), sizeof(h));
+        fprintf(stderr, "[sor_dbg] to-do points finished at ring 1/2/3: %u %u %u, whole cloud: %u\n", h[1], h[2], h[3], h[0]);
+        unsigned int z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sor_dbg), z, sizeof(z));
+    }
+#endif
+    hipLaunchKernelGGL(sor_stats, dim3(B), dim3(256), 0, st, avg, off, std_ratio, stats);
     hipLaunchKernelGGL(sor_flags, dim3(tiles), dim3(256), 0, st, avg, off, B, stats, masks, tile_cnt);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
     hipLaunchKernelGGL(sor_scatter, dim3(tiles), dim3(256), 0, st, xyz, rgb, off, B, masks, tile_cnt, out_xyz64,

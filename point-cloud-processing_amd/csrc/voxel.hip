@@ -198,6 +198,15 @@ vox_reduce(const unsigned long long* __restrict__ keys, const unsigned int* __re
     }
 }
 
+// Bits the sort has to look at: 48 cell bits + the cloud number's.  The padding keys (all ones) stay the largest under
+// any prefix of the bits, and real keys are zero above the cloud bits, so the order equals the full 64-bit order.
+static unsigned int vox_sort_end_bit(int B)
+{
+    unsigned int bits = 1;
+    while (bits < 16 && (1 << bits) < B) ++bits;
+    return 48u + bits;
+}
+
 static size_t vox_sort_temp_bytes(int64_t cap)
 {
     size_t bytes = 0;
@@ -277,7 +286,7 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
     size_t temp_bytes = L.temp_bytes;
     PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.temp), temp_bytes, (const unsigned long long*)keys_in,
                                           keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
-                                          64u, st));
+                                          vox_sort_end_bit(B), st));
     hipLaunchKernelGGL(vox_heads, dim3(tiles), dim3(256), 0, st, keys_out, off, B, masks, tile_cnt);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
     hipLaunchKernelGGL(vox_reduce, dim3(tiles), dim3(256), 0, st, keys_out, vals_out, xyz, rgb, off, B, masks,

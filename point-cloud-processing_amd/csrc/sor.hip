@@ -198,25 +198,25 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
 #ifndef SORC_CAND
 #define SORC_CAND 256          // candidates staged per wave and chunk (FP64 x,y,z: 6 KB)
 #endif
-#define SORC_BATCH 8           // candidates scanned between two queue checks
-#define SORC_QCAP 32           // queue slots per lane (a drain is forced while more than QCAP - BATCH are used): deep
-                               // queues keep the lockstep drains rare and well filled — with 16 slots a wave ran ~220
-                               // insertion passes for ~40 queued candidates per lane, most of them for a handful of lanes.
-                               // A slot holds the candidate's 16-bit position in the staged chunk, not its distance
-                               // (recomputed exactly at the drain)
 #ifndef SORC_WAVES
-#define SORC_WAVES 2           // waves per workgroup (20 KB of LDS: seven workgroups = fourteen waves per CU)
+#define SORC_WAVES 2           // waves per workgroup (24 KB of LDS: six workgroups = twelve waves per CU)
 #endif
 
+// Sorted insertion as a min/max bubble: the candidate travels up the ascending array, every slot keeps the smaller of
+// (slot, traveller) and passes the larger on; the largest value falls off the end.  Two FP64 instructions per slot and
+// no compare / select pairs (five per slot); min and max return one of their operands unchanged, so the array holds the
+// same values as the compare-and-shift form.  d must not be NaN (callers pass DBL_MAX for "nothing to insert").
 template <int KCAP>
 __device__ __forceinline__ void sor_insert1(double (&best)[KCAP], double d)
 {
-    bool c[KCAP];
 #pragma unroll
-    for (int t = 0; t < KCAP; ++t) c[t] = best[t] > d;                // ascending array: true from the insert position on
-#pragma unroll
-    for (int t = KCAP - 1; t > 0; --t) best[t] = c[t - 1] ? best[t - 1] : (c[t] ? d : best[t]);
-    best[0] = c[0] ? d : best[0];
+    for (int t = 0; t < KCAP; ++t) {
+        double lo, up;
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(best[t]), "v"(d));
+        asm("v_max_f64 %0, %1, %2" : "=v"(up) : "v"(best[t]), "v"(d));
+        best[t] = lo;
+        d = up;
+    }
 }
 
 __device__ __forceinline__ long long sor_rl64(long long v, int lane)
@@ -240,7 +240,8 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
     // six FP32 operations instead of eight FP64 ones.  (Gathering the exact coordinates from global memory instead
     // made the kernel texture-address bound: 64 lanes x 3 loads, each its own cache line, per queued candidate.)
     __shared__ double cand_s[SORC_WAVES][3][SORC_CAND];
-    __shared__ unsigned short queue_s[SORC_WAVES][SORC_QCAP + 1][64];     // last row: dump slot of the branch-free push
+    __shared__ float4 cand32_s[SORC_WAVES][SORC_CAND];                    // the same candidates rounded to float, for the filter
+    __shared__ unsigned int pass_s[SORC_WAVES][SORC_CAND / 32][64];       // per lane: one bit per staged candidate that passed
     const int lane = pcp_lane(), wave = threadIdx.x >> 6;
     const long long n = offsets[B];
     const long long j0 = ((long long)blockIdx.x * SORC_WAVES + wave) * 64;
@@ -256,7 +257,8 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
     const int k = (long long)nb < M ? nb : (int)M;
     const double px = sxyz[3 * jj], py = sxyz[3 * jj + 1], pz = sxyz[3 * jj + 2];
     double (*cand)[SORC_CAND] = cand_s[wave];
-    unsigned short (*queue)[64] = queue_s[wave];
+    float4* cand32 = cand32_s[wave];
+    unsigned int (*passw)[64] = pass_s[wave];
     double best[KCAP];
 #pragma unroll
     for (int t = 0; t < KCAP; ++t) best[t] = DBL_MAX;
@@ -267,7 +269,6 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
     const double lim = cell * (1.0 - 1e-9);
     const double lim2 = lim * lim;
     double tau = lim2;
-    int qn = 0;
 #ifdef SORC_STATS
     int st_drain = 0, st_ins = 0, st_push = 0, st_grp = 0, st_cand = 0;
     unsigned long long tm_search = 0, tm_stage = 0, tm_scan = 0, tm_drain = 0, tm0 = __builtin_amdgcn_s_memtime(), tmx;
@@ -344,34 +345,47 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
         const double emargin = 0x1p-20 * (omag + 2.0 * Rmax);
         auto float_bound = [&](double t) -> float {
             const double r = sqrt(t) + emargin;
-            return (float)(r * r * (1.0 + 0x1p-18));
+            return (float)(r * r * (1.0 + 0x1p-18));       // >= 16 float ulps above r^2: covers the strict sign test too
         };
         float tau32 = float_bound(tau);
-        auto drain = [&]() {                                          // must run before the staged chunk is replaced
+        // Drain of one staged chunk: every lane walks ITS pass bits (most significant first = staging order) — two
+        // candidates per trip so that the LDS gathers of one overlap the insertion of the other —, reads the FP64
+        // coordinates back, computes the exact distance the way the oracle does and bubbles it into its top-k.  The
+        // trips run in lockstep until the slowest lane is through.
+        auto drain = [&](int nwords) {
 #ifdef SORC_STATS
             ++st_drain;
             SORC_T(tm_scan);
 #endif
-            for (int s0 = 0; s0 < SORC_QCAP; s0 += 4) {
-                if (!__any(s0 < qn)) break;                           // wave-uniform: queues fill from slot 0 up
-                double d[4];
+            int wi = 0;
+            unsigned int m = passw[0][lane];
+            for (;;) {
+                // lanes whose word is used up move on to their next non-empty one
+                while (m == 0u && wi + 1 < nwords) { ++wi; m = passw[wi][lane]; }
+                if (!__any(m != 0u)) break;
+                double d[2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {                         // four exact distances in flight
-                    const bool live = s0 + u < qn;
-                    const int c = live ? (int)queue[s0 + u][lane] : 0;            // position in the staged chunk
+                for (int u = 0; u < 2; ++u) {
+                    const bool live = m != 0u;
+                    const int bit = live ? __clz(m) : 0;
+                    m &= ~(0x80000000u >> bit);                       // no-op on an empty word (bit 31 of 0)
+                    const int c = live ? wi * 32 + bit : 0;
                     const double dx = px - cand[0][c], dy = py - cand[1][c], dz = pz - cand[2][c];
                     d[u] = live ? ((dx * dx) + (dy * dy)) + (dz * dz) : DBL_MAX;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (__any(d[u] < tau)) {                          // float-margin false positives and stale entries stop here
+                for (int u = 0; u < 2; ++u) {
+                    // the bound a value must beat to enter: exact when every slot is in use (k == KCAP), else the
+                    // (only larger) bound of the last drain; float-margin false positives stop here
+                    const double bound = k == KCAP ? fmin(tau, best[KCAP - 1]) : tau;
+                    if (__any(d[u] < bound)) {
 #ifdef SORC_STATS
                         ++st_ins;
 #endif
-                        sor_insert1<KCAP>(best, d[u] < tau ? d[u] : DBL_MAX);
+                        sor_insert1<KCAP>(best, d[u] < bound ? d[u] : DBL_MAX);
                     }
+                }
             }
-            qn = 0;
             tau = fmin(lim2, sor_kth<KCAP>(best, k));
             tau32 = float_bound(tau);
             SORC_T(tm_drain);
@@ -380,29 +394,32 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
             const int cn = N - cb < SORC_CAND ? N - cb : SORC_CAND;
             for (int i = lane; i < cn; i += 64) {                     // stage: consecutive lanes read consecutive sorted points
                 const long long g = sorted_pos(cb + i);
-                cand[0][i] = sxyz[3 * g]; cand[1][i] = sxyz[3 * g + 1]; cand[2][i] = sxyz[3 * g + 2];
+                const double x = sxyz[3 * g], y = sxyz[3 * g + 1], z = sxyz[3 * g + 2];
+                cand[0][i] = x; cand[1][i] = y; cand[2][i] = z;
+                cand32[i] = make_float4((float)x, (float)y, (float)z, 0.f);
             }
             SORC_T(tm_stage);
-            for (int c0 = 0; c0 < cn; c0 += SORC_BATCH) {
-                if (__any(qn > SORC_QCAP - SORC_BATCH)) drain();
-                float d[SORC_BATCH];
+            // filter: 32 candidates per word; the sign of (float distance - bound) is shifted into the word, one
+            // v_alignbit per candidate, so a candidate costs eight VALU instructions and no LDS write.  Strictly below
+            // the bound here, at or below it in the margin analysis: float_bound() leaves several ulps of room.
+            const int nwords = (cn + 31) >> 5;
+            for (int w = 0; w < nwords; ++w) {
+                unsigned int m = 0u;
 #pragma unroll
-                for (int u = 0; u < SORC_BATCH; ++u) {                // all LDS broadcast reads of the batch in flight together
-                    const int c = c0 + u < cn ? c0 + u : cn - 1;      // a repeated last candidate is filtered below
-                    const float dx = qx - (float)cand[0][c], dy = qy - (float)cand[1][c], dz = qz - (float)cand[2][c];
-                    d[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                for (int u = 0; u < 32; ++u) {                        // rows past cn hold stale data: masked below
+                    const float4 c = cand32[w * 32 + u];
+                    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+                    const float t = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) - tau32;
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);     // m = m << 1 | sign(t)
                 }
-#pragma unroll
-                for (int u = 0; u < SORC_BATCH; ++u) {                // branch-free push: losers write the dump row
-                    const bool win = act && c0 + u < cn && d[u] <= tau32;
-                    queue[win ? qn : SORC_QCAP][lane] = (unsigned short)(c0 + u);
-                    qn += win ? 1 : 0;
+                const int left = cn - w * 32;                         // candidates of this word that exist
+                const unsigned int valid = left >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> left);
+                passw[w][lane] = act ? (m & valid) : 0u;
 #ifdef SORC_STATS
-                    st_push += win ? 1 : 0;
+                st_push += act ? __popc(m & valid) : 0;
 #endif
-                }
             }
-            drain();                                                  // queued positions refer to this chunk
+            drain(nwords);                                            // pass bits refer to this chunk
         }
     }
     const bool done = use && sor_kth<KCAP>(best, k) < lim2;           // k real entries, all inside the first ring

@@ -12,5 +12,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 tools/bench_configs.py $* > "$OUT.fetch.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 tools/bench_configs.py $* > "$OUT.write.log" 2>&1
 timeout -s KILL 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/sq" -- python3 tools/bench_configs.py $* > "$OUT.sq.log" 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d "$OUT/sq2" -- python3 tools/bench_configs.py $* > "$OUT.sq2.log" 2>&1
 python3 tools/summarise_profiles.py "$OUT" "$TAG"
 grep "^{" "$OUT.plain.log" > "$PWD/gpurun_out/${TAG}_bench_lines.json"

@@ -17,7 +17,7 @@ if ks:
 
 OURS = ("fps_", "k1_", "pcp_", "crop_", "gather", "pack", "sor_", "vox_", "rocprim")
 acc = defaultdict(lambda: defaultdict(list))
-for sub in ("fetch", "write", "sq"):
+for sub in ("fetch", "write", "sq", "sq2"):
     for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]

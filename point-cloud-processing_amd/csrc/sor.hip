@@ -32,6 +32,8 @@ sor_gather_sorted(const double* __restrict__ xyz, const unsigned int* __restrict
     sxyz[3 * j] = xyz[3 * i]; sxyz[3 * j + 1] = xyz[3 * i + 1]; sxyz[3 * j + 2] = xyz[3 * i + 2];
 }
 
+// Sorted insertion, compare-and-shift form: every slot decides by itself, so the instructions are independent of each
+// other — the form for the sparsely occupied per-point search below, where a dependent chain is not hidden.
 template <int KCAP>
 __device__ __forceinline__ void sor_insert(double (&best)[KCAP], double d)
 {
@@ -42,6 +44,25 @@ __device__ __forceinline__ void sor_insert(double (&best)[KCAP], double d)
             best[t] = lo > d ? lo : (best[t] > d ? d : best[t]);
         }
         best[0] = best[0] > d ? d : best[0];
+    }
+}
+
+// Sorted insertion as a min/max bubble: the candidate travels up the ascending array, every slot keeps the smaller of
+// (slot, traveller) and passes the larger on; the largest value falls off the end.  Two FP64 instructions per slot and
+// no compare / select pairs (five per slot); min and max return one of their operands unchanged, so the array holds the
+// same values as the compare-and-shift form.  d must not be NaN (callers pass DBL_MAX for "nothing to insert").  The
+// traveller makes the slots a dependent chain: good where many waves per SIMD hide it (sor_knn_coop), measured twice as
+// slow as the compare form in the per-point search (two waves per SIMD).
+template <int KCAP>
+__device__ __forceinline__ void sor_insert1(double (&best)[KCAP], double d)
+{
+#pragma unroll
+    for (int t = 0; t < KCAP; ++t) {
+        double lo, up;
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(best[t]), "v"(d));
+        asm("v_max_f64 %0, %1, %2" : "=v"(up) : "v"(best[t]), "v"(d));
+        best[t] = lo;
+        d = up;
     }
 }
 
@@ -196,28 +217,12 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
 // cells to be covered.  A lane whose k-th distance is not provably inside the first ring (or whose cloud has no more
 // than k points) is appended to a to-do list that sor_knn finishes with its wider search.
 #ifndef SORC_CAND
-#define SORC_CAND 256          // candidates staged per wave and chunk (FP64 x,y,z: 6 KB)
+#define SORC_CAND 192          // candidates staged per wave and chunk (FP64 x,y,z + float4 + pass words: 9 KB, so that
+                               // LDS allows the sixteen waves per CU the registers allow); 128 / 256 / 512 were slower
 #endif
 #ifndef SORC_WAVES
-#define SORC_WAVES 2           // waves per workgroup (24 KB of LDS: six workgroups = twelve waves per CU)
+#define SORC_WAVES 1           // waves per workgroup: the waves share nothing, and single-wave groups pack best (2 / 4: +4 / +10 %)
 #endif
-
-// Sorted insertion as a min/max bubble: the candidate travels up the ascending array, every slot keeps the smaller of
-// (slot, traveller) and passes the larger on; the largest value falls off the end.  Two FP64 instructions per slot and
-// no compare / select pairs (five per slot); min and max return one of their operands unchanged, so the array holds the
-// same values as the compare-and-shift form.  d must not be NaN (callers pass DBL_MAX for "nothing to insert").
-template <int KCAP>
-__device__ __forceinline__ void sor_insert1(double (&best)[KCAP], double d)
-{
-#pragma unroll
-    for (int t = 0; t < KCAP; ++t) {
-        double lo, up;
-        asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(best[t]), "v"(d));
-        asm("v_max_f64 %0, %1, %2" : "=v"(up) : "v"(best[t]), "v"(d));
-        best[t] = lo;
-        d = up;
-    }
-}
 
 __device__ __forceinline__ long long sor_rl64(long long v, int lane)
 {
@@ -226,8 +231,10 @@ __device__ __forceinline__ long long sor_rl64(long long v, int lane)
     return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 
+// waves per SIMD the register allocation aims at: the sorted top-k (2 x KCAP registers) decides what fits
+#define SORC_EU(KCAP) ((KCAP) <= 20 ? 4 : ((KCAP) <= 24 ? 3 : 2))
 template <int KCAP>
-__global__ void __launch_bounds__(64 * SORC_WAVES)
+__global__ void __launch_bounds__(64 * SORC_WAVES) __attribute__((amdgpu_waves_per_eu(SORC_EU(KCAP), SORC_EU(KCAP))))
 sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restrict__ keys,
              const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
              int nb, double* __restrict__ avg, unsigned int* __restrict__ todo, unsigned int* __restrict__ todo_cnt)

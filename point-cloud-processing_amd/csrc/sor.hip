@@ -34,6 +34,8 @@ sor_gather_sorted(const double* __restrict__ xyz, const unsigned int* __restrict
 
 // Sorted insertion, compare-and-shift form: every slot decides by itself, so the instructions are independent of each
 // other — the form for the sparsely occupied per-point search below, where a dependent chain is not hidden.
+typedef float pcp_f2 __attribute__((ext_vector_type(2)));
+
 template <int KCAP>
 __device__ __forceinline__ void sor_insert(double (&best)[KCAP], double d)
 {
@@ -247,7 +249,9 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
     // six FP32 operations instead of eight FP64 ones.  (Gathering the exact coordinates from global memory instead
     // made the kernel texture-address bound: 64 lanes x 3 loads, each its own cache line, per queued candidate.)
     __shared__ double cand_s[SORC_WAVES][3][SORC_CAND];
-    __shared__ float4 cand32_s[SORC_WAVES][SORC_CAND];                    // the same candidates rounded to float, for the filter
+    // the same candidates rounded to float, for the filter: two per row {x0,x1,y0,y1,z0,z1,-,-} so that a pair goes
+    // through the packed FP32 instructions
+    __shared__ __attribute__((aligned(16))) float cand32_s[SORC_WAVES][SORC_CAND / 2][8];
     __shared__ unsigned int pass_s[SORC_WAVES][SORC_CAND / 32][64];       // per lane: one bit per staged candidate that passed
     const int lane = pcp_lane(), wave = threadIdx.x >> 6;
     const long long n = offsets[B];
@@ -264,7 +268,7 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
     const int k = (long long)nb < M ? nb : (int)M;
     const double px = sxyz[3 * jj], py = sxyz[3 * jj + 1], pz = sxyz[3 * jj + 2];
     double (*cand)[SORC_CAND] = cand_s[wave];
-    float4* cand32 = cand32_s[wave];
+    float (*cand32)[8] = cand32_s[wave];
     unsigned int (*passw)[64] = pass_s[wave];
     double best[KCAP];
 #pragma unroll
@@ -403,21 +407,25 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
                 const long long g = sorted_pos(cb + i);
                 const double x = sxyz[3 * g], y = sxyz[3 * g + 1], z = sxyz[3 * g + 2];
                 cand[0][i] = x; cand[1][i] = y; cand[2][i] = z;
-                cand32[i] = make_float4((float)x, (float)y, (float)z, 0.f);
+                float* c32 = &cand32[i >> 1][i & 1];
+                c32[0] = (float)x; c32[2] = (float)y; c32[4] = (float)z;
             }
             SORC_T(tm_stage);
             // filter: 32 candidates per word; the sign of (float distance - bound) is shifted into the word, one
             // v_alignbit per candidate, so a candidate costs eight VALU instructions and no LDS write.  Strictly below
             // the bound here, at or below it in the margin analysis: float_bound() leaves several ulps of room.
             const int nwords = (cn + 31) >> 5;
+            const pcp_f2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz}, tau2 = {tau32, tau32};
             for (int w = 0; w < nwords; ++w) {
                 unsigned int m = 0u;
 #pragma unroll
-                for (int u = 0; u < 32; ++u) {                        // rows past cn hold stale data: masked below
-                    const float4 c = cand32[w * 32 + u];
-                    const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-                    const float t = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) - tau32;
-                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t), 31);     // m = m << 1 | sign(t)
+                for (int u = 0; u < 32; u += 2) {                     // rows past cn hold stale data: masked below
+                    const float4 xy = *(const float4*)&cand32[w * 16 + (u >> 1)][0];
+                    const float2 zz = *(const float2*)&cand32[w * 16 + (u >> 1)][4];
+                    const pcp_f2 dx = q2x - (pcp_f2){xy.x, xy.y}, dy = q2y - (pcp_f2){xy.z, xy.w}, dz = q2z - (pcp_f2){zz.x, zz.y};
+                    const pcp_f2 t = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx)) - tau2;
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t.x), 31);   // m = m << 1 | sign(t)
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(t.y), 31);
                 }
                 const int left = cn - w * 32;                         // candidates of this word that exist
                 const unsigned int valid = left >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> left);
@@ -435,7 +443,7 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
         int pmax = st_push, psum = st_push;
         for (int dd = 32; dd >= 1; dd >>= 1) { pmax = max(pmax, __shfl_xor(pmax, dd, 64)); psum += __shfl_xor(psum, dd, 64); }
         const int nd = (int)__popcll(__ballot(done));
-        if (blockIdx.x % 8000 == 17 && wave == 1 && lane == 0)
+        if (blockIdx.x % 16000 == 17 && wave == SORC_WAVES - 1 && lane == 0)
             printf("[sorc] blk %d groups %d cand %d drains %d inserts %d push max %d avg %.1f done %d | cycles search %llu stage %llu scan %llu drain %llu\n", blockIdx.x, st_grp, st_cand, st_drain, st_ins, pmax, psum / 64.0, nd, tm_search, tm_stage, tm_scan, tm_drain);
     }
 #endif

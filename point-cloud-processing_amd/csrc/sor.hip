@@ -213,8 +213,8 @@ sor_knn(const double* __restrict__ sxyz, const unsigned long long* __restrict__ 
 // runs (rows x-1..x+1, y-1..y+1, cells zmin-1..zmax+1).  The wave finds the nine runs with eighteen binary searches
 // done side by side by eighteen lanes, stages the runs' points in LDS with coalesced loads, and every lane scans
 // the staged candidates with LDS broadcast reads — no per-lane global gathers, no per-lane binary searches, no
-// divergent row loops.  Candidates that beat a lane's bound go to its LDS queue and the queues are drained in
-// lockstep into a sorted top-k kept in registers (one compare per slot).  Scanning a superset of a lane's own 27
+// divergent row loops.  Candidates that may beat a lane's bound set a bit in its pass words and the lanes drain their
+// bits in lockstep into a sorted top-k kept in registers.  Scanning a superset of a lane's own 27
 // cells cannot change its result: the k smallest distances are a multiset and the ring proof below only needs the 27
 // cells to be covered.  A lane whose k-th distance is not provably inside the first ring (or whose cloud has no more
 // than k points) is appended to a to-do list that sor_knn finishes with its wider search.
@@ -241,13 +241,13 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
              const unsigned int* __restrict__ vals, const long long* __restrict__ offsets, int B, double cell,
              int nb, double* __restrict__ avg, unsigned int* __restrict__ todo, unsigned int* __restrict__ todo_cnt)
 {
-    // The scan runs in FLOAT (candidate coordinates rounded on the fly) and only FILTERS: a candidate whose float
-    // distance is within a rigorous error margin of the lane's bound is queued (its 16-bit position in the staged chunk),
-    // everything else is provably farther than the bound.  The drain reads the queued candidates' FP64 coordinates
-    // back from LDS (a per-lane gather), computes the exact distance the way the oracle does and inserts it into the
-    // sorted top-k — every value that decides anything is exact, and the per-candidate cost is three conversions and
-    // six FP32 operations instead of eight FP64 ones.  (Gathering the exact coordinates from global memory instead
-    // made the kernel texture-address bound: 64 lanes x 3 loads, each its own cache line, per queued candidate.)
+    // The scan runs in FLOAT (candidate coordinates rounded once, at staging) and only FILTERS: a candidate whose float
+    // distance is within a rigorous error margin of the lane's bound gets a pass bit, everything else is provably
+    // farther than the bound.  The drain reads the passed candidates' FP64 coordinates back from LDS (a per-lane
+    // gather), computes the exact distance in Open3D's operation order and inserts it into the sorted top-k — every
+    // value that decides anything is exact, and a candidate costs 4.5 FP32-rate instructions instead of eight FP64 ones.
+    // (Gathering the exact coordinates from global memory instead made the kernel texture-address bound: 64 lanes x 3
+    // loads, each its own cache line, per passed candidate.)
     __shared__ double cand_s[SORC_WAVES][3][SORC_CAND];
     // the same candidates rounded to float, for the filter: two per row {x0,x1,y0,y1,z0,z1,-,-} so that a pair goes
     // through the packed FP32 instructions
@@ -361,7 +361,7 @@ sor_knn_coop(const double* __restrict__ sxyz, const unsigned long long* __restri
         float tau32 = float_bound(tau);
         // Drain of one staged chunk: every lane walks ITS pass bits (most significant first = staging order) — two
         // candidates per trip so that the LDS gathers of one overlap the insertion of the other —, reads the FP64
-        // coordinates back, computes the exact distance the way the oracle does and bubbles it into its top-k.  The
+        // coordinates back, computes the exact distance in Open3D's operation order and bubbles it into its top-k.  The
         // trips run in lockstep until the slowest lane is through.
         auto drain = [&](int nwords) {
 #ifdef SORC_STATS

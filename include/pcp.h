@@ -298,6 +298,11 @@ int pcp_pack_dp3(const float* xyz, const float* rgb, int B, int K, float* out, v
  * sort are sized by it; at most 2^32-1), `cap_out` the row capacity of the
  * outputs; *overflow (device i32, may be NULL) is set when rows were dropped or a
  * grid index left [0,65535] on an axis (results are then unspecified).
+ * `max_extent` (metres) is an optional promise that lets the grid sort run on
+ * 32-bit keys: no cloud's bounding box is longer than this along any axis (for
+ * workspace-cropped clouds: the longest workspace edge).  0 = unknown — always
+ * valid, the sort then covers the full 16 bits per axis.  A cloud that breaks the
+ * promise sets *overflow (results unspecified), it is never silently mis-sorted.
  * ------------------------------------------------------------------------- */
 
 /*
@@ -312,7 +317,7 @@ int pcp_pack_dp3(const float* xyz, const float* rgb, int B, int K, float* out, v
  */
 size_t pcp_voxel_workspace_bytes(int B, int64_t cap_pts);
 int pcp_voxel_downsample(const double* xyz, const float* rgb, const int64_t* offsets, int B,
-                         int64_t cap_pts, double voxel_size,
+                         int64_t cap_pts, double voxel_size, double max_extent,
                          double* out_xyz64, float* out_xyz32, float* out_rgb32, int32_t* out_count,
                          int64_t* out_offsets, int64_t cap_out, int32_t* overflow,
                          void* ws, size_t ws_bytes, void* stream);
@@ -331,6 +336,7 @@ int pcp_voxel_downsample(const double* xyz, const float* rgb, const int64_t* off
 size_t pcp_sor_workspace_bytes(int B, int64_t cap_pts);
 int pcp_statistical_outlier_removal(const double* xyz, const float* rgb, const int64_t* offsets, int B,
                                     int64_t cap_pts, int nb_neighbors, double std_ratio, double cell_size,
+                                    double max_extent,
                                     double* out_xyz64, float* out_xyz32, float* out_rgb32,
                                     int64_t* out_index, int64_t* out_offsets, double* avg_dist,
                                     int64_t cap_out, int32_t* overflow,

@@ -622,7 +622,7 @@ extern "C" size_t pcp_sor_workspace_bytes(int B, int64_t cap_pts)
 
 extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* rgb, const int64_t* offsets,
                                                int B, int64_t cap_pts, int nb_neighbors, double std_ratio,
-                                               double cell_size, double* out_xyz64, float* out_xyz32,
+                                               double cell_size, double max_extent, double* out_xyz64, float* out_xyz32,
                                                float* out_rgb32, int64_t* out_index, int64_t* out_offsets,
                                                double* avg_dist, int64_t cap_out, int32_t* overflow, void* ws,
                                                size_t ws_bytes, void* stream)
@@ -658,12 +658,11 @@ extern "C" int pcp_statistical_outlier_removal(const double* xyz, const float* r
 
     PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
     hipLaunchKernelGGL(vox_minbound, dim3((nblk + VOX_MB_ITERS - 1) / VOX_MB_ITERS), dim3(256), 0, st, xyz, off, B, minb);
-    hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, cell_size,
-                       keys_in, vals_in, overflow);
-    size_t temp_bytes = L.v.temp_bytes;
-    PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.v.temp), temp_bytes, (const unsigned long long*)keys_in,
-                                          keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
-                                          vox_sort_end_bit(B), st));
+    {
+        const int rc = vox_sorted_keys(xyz, off, B, cap_pts, minb, cell_size, max_extent, keys_in, keys_out, vals_in,
+                                       vals_out, (void*)(w + L.v.temp), L.v.temp_bytes, overflow, st);
+        if (rc != PCP_OK) return rc;
+    }
     hipLaunchKernelGGL(sor_gather_sorted, dim3(nblk), dim3(256), 0, st, xyz, vals_out, off, B, sxyz);
     unsigned int* todo = (unsigned int*)(w + L.todo);
     unsigned int* todo_cnt = (unsigned int*)(w + L.todo_cnt);

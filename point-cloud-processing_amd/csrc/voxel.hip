@@ -99,29 +99,49 @@ vox_minbound(const double* __restrict__ xyz, const long long* __restrict__ offse
     flush();
 }
 
+// bf = 0: 64-bit keys cloud<<48 | ix<<32 | iy<<16 | iz.  bf > 0 (the caller promised a bounding-box edge, so every
+// grid index fits bf bits): 32-bit keys cloud<<3bf | ix<<2bf | iy<<bf | iz into keys32 — a third of the sort's bytes and
+// half its passes; an index that does not fit breaks the promise and raises the overflow flag.
 __global__ void __launch_bounds__(256)
 vox_keys(const double* __restrict__ xyz, const long long* __restrict__ offsets, int B, long long cap,
          const unsigned long long* __restrict__ minb, double voxel, unsigned long long* __restrict__ keys,
-         unsigned int* __restrict__ vals, int* __restrict__ overflow)
+         unsigned int* __restrict__ keys32, int bf, unsigned int* __restrict__ vals, int* __restrict__ overflow)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap) return;
     const long long n = offsets[B];
     vals[i] = (unsigned int)i;
-    if (i >= n) { keys[i] = VOX_KEY_PAD; return; }
+    if (i >= n) {
+        if (bf) keys32[i] = 0xFFFFFFFFu; else keys[i] = VOX_KEY_PAD;
+        return;
+    }
     const int b = vox_cloud_of(offsets, B, i);
-    unsigned long long key = (unsigned long long)b << 48;
+    const long long qmax = bf ? (1ll << bf) - 1 : (long long)VOX_AXIS_MAX;
+    long long q[3];
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double origin = vox_unord(minb[3 * b + c]) - voxel * 0.5;     // GetMinBound() - voxel_size*0.5
         const double r = floor((xyz[3 * i + c] - origin) / voxel);
-        long long q = (long long)r;
-        if (!(r >= 0.0) || r > (double)VOX_AXIS_MAX) { bad = true; q = r > 0.0 ? VOX_AXIS_MAX : 0; }
-        key |= (unsigned long long)q << (16 * (2 - c));
+        q[c] = (long long)r;
+        if (!(r >= 0.0) || r > (double)qmax) { bad = true; q[c] = r > 0.0 ? qmax : 0; }
     }
     if (bad && overflow) *overflow = 1;
-    keys[i] = key;
+    if (bf) keys32[i] = (unsigned int)((((((unsigned long long)b << bf) | (unsigned long long)q[0]) << bf) | (unsigned long long)q[1]) << bf | (unsigned long long)q[2]);
+    else keys[i] = ((unsigned long long)b << 48) | ((unsigned long long)q[0] << 32) | ((unsigned long long)q[1] << 16) | (unsigned long long)q[2];
+}
+
+// sorted 32-bit keys back into the 64-bit layout every later kernel reads
+__global__ void __launch_bounds__(256)
+vox_unpack_keys(const unsigned int* __restrict__ keys32, const long long* __restrict__ offsets, int B, long long cap,
+                int bf, unsigned long long* __restrict__ keys)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    if (i >= offsets[B]) { keys[i] = VOX_KEY_PAD; return; }
+    const unsigned int k = keys32[i], m = (1u << bf) - 1u;
+    keys[i] = ((unsigned long long)(k >> (3 * bf)) << 48) | ((unsigned long long)((k >> (2 * bf)) & m) << 32) |
+              ((unsigned long long)((k >> bf) & m) << 16) | (unsigned long long)(k & m);
 }
 
 // grid: tiles of 1024 sorted rows; block 256 (wave w, round r → word w*4+r)
@@ -198,23 +218,66 @@ vox_reduce(const unsigned long long* __restrict__ keys, const unsigned int* __re
     }
 }
 
-// Bits the sort has to look at: 48 cell bits + the cloud number's.  The padding keys (all ones) stay the largest under
-// any prefix of the bits, and real keys are zero above the cloud bits, so the order equals the full 64-bit order.
-static unsigned int vox_sort_end_bit(int B)
+static unsigned int vox_cloud_bits(int B)
 {
     unsigned int bits = 1;
     while (bits < 16 && (1 << bits) < B) ++bits;
-    return 48u + bits;
+    return bits;
+}
+
+// Bits per axis of the packed 32-bit keys, or 0 for the 64-bit keys: with the caller's promise `max_extent` a grid index
+// is at most floor(max_extent / cell + 1/2) + 1 (origin = min bound - cell/2; one more for the rounding of the quotient).
+static int vox_pack_bits(int B, double max_extent, double cell)
+{
+    if (!(max_extent > 0.0) || !(max_extent < 1e300)) return 0;
+    const double cells = floor(max_extent / cell + 0.5) + 2.0;       // indices 0 .. cells-1
+    if (!(cells < 65536.0)) return 0;
+    int bf = 1;
+    while ((double)(1 << bf) < cells) ++bf;
+    return (int)vox_cloud_bits(B) + 3 * bf <= 32 ? bf : 0;
 }
 
 static size_t vox_sort_temp_bytes(int64_t cap)
 {
-    size_t bytes = 0;
+    size_t bytes = 0, bytes32 = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned long long*)nullptr,
                                              (unsigned long long*)nullptr, (const unsigned int*)nullptr,
                                              (unsigned int*)nullptr, (size_t)cap, 0u, 64u, (hipStream_t)0);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return bytes;
+    e = rocprim::radix_sort_pairs(nullptr, bytes32, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                                  (const unsigned int*)nullptr, (unsigned int*)nullptr, (size_t)cap, 0u, 32u,
+                                  (hipStream_t)0);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return bytes > bytes32 ? bytes : bytes32;
+}
+
+// Keys of every row (pads included), stable sort by key, 64-bit sorted keys in keys_out, source rows in vals_out.
+// keys_in doubles as the two 32-bit key arrays of the packed path.
+static int vox_sorted_keys(const double* xyz, const long long* off, int B, int64_t cap_pts, const unsigned long long* minb,
+                           double cell, double max_extent, unsigned long long* keys_in, unsigned long long* keys_out,
+                           unsigned int* vals_in, unsigned int* vals_out, void* temp, size_t temp_bytes, int* overflow,
+                           hipStream_t st)
+{
+    const unsigned nblk = (unsigned)((cap_pts + 255) / 256);
+    const int bf = vox_pack_bits(B, max_extent, cell);
+    unsigned int* k32_in = (unsigned int*)keys_in;
+    unsigned int* k32_out = k32_in + cap_pts;
+    hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, cell, keys_in, k32_in,
+                       bf, vals_in, overflow);
+    if (bf) {
+        PCP_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned int*)k32_in, k32_out,
+                                              (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
+                                              vox_cloud_bits(B) + 3u * (unsigned)bf, st));
+        hipLaunchKernelGGL(vox_unpack_keys, dim3(nblk), dim3(256), 0, st, (const unsigned int*)k32_out, off, B,
+                           (long long)cap_pts, bf, keys_out);
+    } else {
+        // 48 cell bits + the cloud number's: the padding keys (all ones) stay the largest under any prefix of the bits and
+        // real keys are zero above the cloud bits, so the order equals the full 64-bit order
+        PCP_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned long long*)keys_in, keys_out,
+                                              (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
+                                              48u + vox_cloud_bits(B), st));
+    }
+    return PCP_OK;
 }
 
 struct VoxLayout {
@@ -248,7 +311,8 @@ extern "C" size_t pcp_voxel_workspace_bytes(int B, int64_t cap_pts)
 }
 
 extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const int64_t* offsets, int B,
-                                    int64_t cap_pts, double voxel_size, double* out_xyz64, float* out_xyz32,
+                                    int64_t cap_pts, double voxel_size, double max_extent, double* out_xyz64,
+                                    float* out_xyz32,
                                     float* out_rgb32, int32_t* out_count, int64_t* out_offsets,
                                     int64_t cap_out, int32_t* overflow, void* ws, size_t ws_bytes,
                                     void* stream)
@@ -281,12 +345,11 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
 
     PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
     hipLaunchKernelGGL(vox_minbound, dim3((nblk + VOX_MB_ITERS - 1) / VOX_MB_ITERS), dim3(256), 0, st, xyz, off, B, minb);
-    hipLaunchKernelGGL(vox_keys, dim3(nblk), dim3(256), 0, st, xyz, off, B, (long long)cap_pts, minb, voxel_size,
-                       keys_in, vals_in, overflow);
-    size_t temp_bytes = L.temp_bytes;
-    PCP_HIP_TRY(rocprim::radix_sort_pairs((void*)(w + L.temp), temp_bytes, (const unsigned long long*)keys_in,
-                                          keys_out, (const unsigned int*)vals_in, vals_out, (size_t)cap_pts, 0u,
-                                          vox_sort_end_bit(B), st));
+    {
+        const int rc = vox_sorted_keys(xyz, off, B, cap_pts, minb, voxel_size, max_extent, keys_in, keys_out, vals_in,
+                                       vals_out, (void*)(w + L.temp), L.temp_bytes, overflow, st);
+        if (rc != PCP_OK) return rc;
+    }
     hipLaunchKernelGGL(vox_heads, dim3(tiles), dim3(256), 0, st, keys_out, off, B, masks, tile_cnt);
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(1), dim3(256), 0, st, tile_cnt, tiles, total);
     hipLaunchKernelGGL(vox_reduce, dim3(tiles), dim3(256), 0, st, keys_out, vals_out, xyz, rgb, off, B, masks,

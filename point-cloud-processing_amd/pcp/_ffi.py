@@ -89,10 +89,10 @@ def load_library():
     L.pcp_pack_dp3.argtypes = [vp, vp, i32, i32, vp, vp]; L.pcp_pack_dp3.restype = i32
     f64 = C.c_double
     L.pcp_voxel_workspace_bytes.argtypes = [i32, i64]; L.pcp_voxel_workspace_bytes.restype = sz
-    L.pcp_voxel_downsample.argtypes = [vp, vp, vp, i32, i64, f64, vp, vp, vp, vp, vp, i64, vp, vp, sz, vp]
+    L.pcp_voxel_downsample.argtypes = [vp, vp, vp, i32, i64, f64, f64, vp, vp, vp, vp, vp, i64, vp, vp, sz, vp]
     L.pcp_voxel_downsample.restype = i32
     L.pcp_sor_workspace_bytes.argtypes = [i32, i64]; L.pcp_sor_workspace_bytes.restype = sz
-    L.pcp_statistical_outlier_removal.argtypes = [vp, vp, vp, i32, i64, i32, f64, f64, vp, vp, vp, vp, vp, vp,
+    L.pcp_statistical_outlier_removal.argtypes = [vp, vp, vp, i32, i64, i32, f64, f64, f64, vp, vp, vp, vp, vp, vp,
                                                   i64, vp, vp, sz, vp]
     L.pcp_statistical_outlier_removal.restype = i32
     _lib = L

@@ -94,12 +94,13 @@ def process_point_clouds_batched(clouds, num_points=NUM_POINTS, voxel_size=None,
     if filtered:
         c32 = c64[:total].float().contiguous()
         x64 = x64[:total].contiguous()
+        ext = max(h - l for l, h in zip(lo, hi))          # cropped clouds (and their voxel means) lie inside the box
         if voxel_size is not None:
-            v, out_off = ops.voxel_downsample(x64, c32, out_off, float(voxel_size))
+            v, out_off = ops.voxel_downsample(x64, c32, out_off, float(voxel_size), max_extent=ext)
             total = int(out_off[-1].item())
             x64, c32 = v["xyz64"][:total].contiguous(), v["rgb32"][:total].contiguous()
         if sor is not None and total > 0:
-            s, out_off = ops.statistical_outlier_removal(x64, c32, out_off, int(sor[0]), float(sor[1]))
+            s, out_off = ops.statistical_outlier_removal(x64, c32, out_off, int(sor[0]), float(sor[1]), max_extent=ext)
             total = int(out_off[-1].item())
             x64, c32 = s["xyz64"][:total].contiguous(), s["rgb32"][:total].contiguous()
         if total == 0:

@@ -301,9 +301,11 @@ def _csr_outputs(n, device, rgb, want_index=False):
     return out
 
 
-def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None):
+def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None, max_extent=None):
     """Open3D-semantics voxel-grid mean filter on B CSR clouds (pcp_voxel_downsample).
-    xyz (n,3) f64, rgb (n,3) f32 or None, offsets (B+1) i64 → dict(xyz64, xyz32, rgb32, count), out_offsets."""
+    xyz (n,3) f64, rgb (n,3) f32 or None, offsets (B+1) i64 → dict(xyz64, xyz32, rgb32, count), out_offsets.
+    max_extent: optional promise (metres) that no cloud's bounding box is longer along any axis — e.g. the longest
+    workspace edge for cropped clouds; lets the grid sort run on 32-bit keys.  A broken promise raises the overflow flag."""
     _require_cuda(xyz, offsets)
     _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
     if rgb is not None:
@@ -319,11 +321,17 @@ def voxel_downsample(xyz, rgb, offsets, voxel_size, cap_pts=None):
     out["count"] = torch.empty((n,), dtype=torch.int32, device=dev)
     out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
-    _call(dev, L.pcp_voxel_downsample, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, float(voxel_size), _ptr(out["xyz64"]),
+    _call(dev, L.pcp_voxel_downsample, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, float(voxel_size),
+          float(max_extent or 0.0), _ptr(out["xyz64"]),
           _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["count"]), _ptr(out_off), n,
           _ptr(ovf), _ptr(ws), nb)
     out["overflow"] = ovf
     return out, out_off
+
+
+def workspace_extent(params):
+    """Longest edge of the workspace box of `params`: the max_extent promise for clouds cropped to it."""
+    return max(float(params.ws_hi[c]) - float(params.ws_lo[c]) for c in range(3))
 
 
 def sor_cell_size(xyz, n_clouds, nb_neighbors=20):
@@ -341,9 +349,11 @@ def sor_cell_size(xyz, n_clouds, nb_neighbors=20):
     return max(cell, max(ext) / 60000.0)          # keep every grid index inside 16 bits
 
 
-def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.0, cell_size=None, cap_pts=None):
+def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.0, cell_size=None, cap_pts=None,
+                                max_extent=None):
     """Open3D-semantics statistical outlier removal on B CSR clouds (pcp_statistical_outlier_removal).
-    cell_size None → sor_cell_size().  → dict(xyz64, xyz32, rgb32, index, avg), out_offsets."""
+    cell_size None → sor_cell_size().  max_extent: see voxel_downsample.
+    → dict(xyz64, xyz32, rgb32, index, avg), out_offsets."""
     _require_cuda(xyz, offsets)
     _chk(xyz, torch.float64, "xyz"); _chk(offsets, torch.int64, "offsets")
     if rgb is not None:
@@ -362,7 +372,7 @@ def statistical_outlier_removal(xyz, rgb, offsets, nb_neighbors=20, std_ratio=2.
     out_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
     _call(dev, L.pcp_statistical_outlier_removal, _ptr(xyz), _ptr(rgb), _ptr(offsets), B, n, int(nb_neighbors),
-          float(std_ratio), float(cell_size), _ptr(out["xyz64"]),
+          float(std_ratio), float(cell_size), float(max_extent or 0.0), _ptr(out["xyz64"]),
           _ptr(out["xyz32"]), _ptr(out["rgb32"]), _ptr(out["index"]),
           _ptr(out_off), _ptr(out["avg"]), n, _ptr(ovf), _ptr(ws), nb)
     out["overflow"] = ovf

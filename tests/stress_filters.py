@@ -47,7 +47,10 @@ def main():
         rgb = torch.from_numpy(np.concatenate(cols)).cuda()
         offt = torch.from_numpy(off).cuda()
         voxel = float(rng.choice([0.002, 0.01, 0.05, 0.3]))
-        v, voff = ops.voxel_downsample(xyz, rgb, offt, voxel)
+        # half of the cases promise a bounding-box edge (a true one, up to 1.5x loose): the packed 32-bit sort keys
+        true_ext = max(float((c.max(0) - c.min(0)).max()) for c in clouds)
+        ext = true_ext * float(rng.uniform(1.0, 1.5)) if rng.random() < 0.5 else None
+        v, voff = ops.voxel_downsample(xyz, rgb, offt, voxel, max_extent=ext)
         voff = voff.cpu().numpy()
         for b in range(B):
             ref = cbind.voxel_downsample(clouds[b], cols[b], voxel)
@@ -62,7 +65,7 @@ def main():
         nb, sr = int(rng.choice([1, 5, 8, 16, 20, 24, 32])), float(rng.choice([0.5, 1.0, 2.0, 3.0]))
         cell = None if rng.random() < 0.5 else float(rng.choice([0.003, 0.02, 0.1, 1.0]))
         try:
-            s, soff = ops.statistical_outlier_removal(xyz, rgb, offt, nb, sr, cell_size=cell)
+            s, soff = ops.statistical_outlier_removal(xyz, rgb, offt, nb, sr, cell_size=cell, max_extent=ext)
         except Exception as e:                               # an explicit cell too small for a far-flung cloud is refused
             stats["sor_refused"] += 1
             n += 1

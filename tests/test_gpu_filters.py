@@ -50,6 +50,39 @@ def test_voxel_downsample_matches_oracle(voxel, pad):
     assert int(out["count"][:oo[-1]].sum().item()) == n          # every point lands in exactly one voxel
 
 
+def test_extent_promise_selects_packed_keys_with_identical_results():
+    """max_extent (a promise on the clouds' bounding boxes) only changes the sort keys (32-bit packed instead of 64-bit):
+    voxel means, kept rows and mean distances are the same bit for bit; a broken promise raises the overflow flag."""
+    from pcp import ops
+    clouds = _clouds(3)
+    rng = np.random.default_rng(9)
+    cols = [rng.random((len(c), 3)).astype(np.float32) for c in clouds]
+    xyz, off = _csr(clouds); rgb, _ = _csr(cols, dtype=np.float32)
+    tx, tr, to = torch.from_numpy(xyz).cuda(), torch.from_numpy(rgb).cuda(), torch.from_numpy(off).cuda()
+    ext = max(float((c.max(0) - c.min(0)).max()) for c in clouds if len(c))
+    for voxel in (0.05, 0.005):
+        a, ao = ops.voxel_downsample(tx, tr, to, voxel)
+        for hint in (ext, 1.37 * ext):
+            b, bo = ops.voxel_downsample(tx, tr, to, voxel, max_extent=hint)
+            assert int(b["overflow"].item()) == 0
+            assert torch.equal(ao, bo)
+            n = int(ao[-1])
+            for k in ("xyz64", "xyz32", "rgb32", "count"):
+                assert torch.equal(a[k][:n], b[k][:n]), (voxel, hint, k)
+    sa, sao = ops.statistical_outlier_removal(tx, tr, to, 16, 1.5)
+    sb, sbo = ops.statistical_outlier_removal(tx, tr, to, 16, 1.5, max_extent=ext)
+    assert int(sb["overflow"].item()) == 0 and torch.equal(sao, sbo)
+    n = int(sao[-1])
+    for k in ("xyz64", "rgb32", "index"):
+        assert torch.equal(sa[k][:n], sb[k][:n]), k
+    assert torch.equal(sa["avg"], sb["avg"])
+    # a promise the data breaks must not pass silently
+    bad, _ = ops.voxel_downsample(tx, tr, to, 0.005, max_extent=0.25 * ext)
+    assert int(bad["overflow"].item()) == 1
+    bad, _ = ops.statistical_outlier_removal(tx, tr, to, 16, 1.5, cell_size=0.02, max_extent=0.25 * ext)
+    assert int(bad["overflow"].item()) == 1
+
+
 def test_voxel_downsample_no_colour_and_empty_batch():
     from pcp import ops
     xyz, off = _csr(_clouds(5)[:1])

@@ -31,10 +31,11 @@ def config3(B):
     st = {}
     def f1(): st["o"], st["off"] = s1.run(depth, rgb, p)
     f1(); M = int(st["off"][-1].item())
-    def f2(): st["v"], st["voff"] = ops.voxel_downsample(st["o"]["xyz64"], st["o"]["rgb32"], st["off"], 0.005, cap_pts=M)
+    ext = ops.workspace_extent(p) if os.environ.get("PCP_NO_EXTENT_HINT") is None else None
+    def f2(): st["v"], st["voff"] = ops.voxel_downsample(st["o"]["xyz64"], st["o"]["rgb32"], st["off"], 0.005, cap_pts=M, max_extent=ext)
     f2(); V = int(st["voff"][-1].item())
     st["cell"] = ops.sor_cell_size(st["v"]["xyz64"][:V], B, 20) * float(os.environ.get("PCP_SOR_CELL_SCALE", "1"))
-    def f3(): st["s"], st["soff"] = ops.statistical_outlier_removal(st["v"]["xyz64"], st["v"]["rgb32"], st["voff"], 20, 2.0, st["cell"], cap_pts=V)
+    def f3(): st["s"], st["soff"] = ops.statistical_outlier_removal(st["v"]["xyz64"], st["v"]["rgb32"], st["voff"], 20, 2.0, st["cell"], cap_pts=V, max_extent=ext)
     f3(); S = int(st["soff"][-1].item())
     mx = int((st["soff"][1:] - st["soff"][:-1]).max().item())
     plan = ops.Fps(B, S, mx, K, depth.device)

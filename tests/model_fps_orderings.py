@@ -187,3 +187,67 @@ if __name__ == '__main__':
     o = np.argsort(h4, kind='stable')
     for pd in (1, 3, 4, 8, 1000):
         simulate_pstar(P, o, samples, pd, tag=f'p* trigger, list {pd}')
+
+
+def simulate_lazy(P, order, samples, PEND, mode, ALPHA=0.95, BS=64, tag=''):
+    """Deferred rounds as in fps_lazy_rounds.  mode 'ub': a bucket a sample could change becomes DIRTY at once (its key an
+    upper bound, flushed when the bound reaches tau or the list is full) — the kernel's scheme.  mode 'pstar+ub': it stays
+    CLEAN (exact key, still a candidate) while no pending sample reaches its arg-max point; only such a hit makes it dirty."""
+    S = P[order]; M = len(S); NB = (M + BS - 1) // BS
+    pad = NB * BS - M
+    Sp = np.concatenate([S, np.repeat(S[-1:], pad, 0)]) if pad else S
+    B3 = Sp.reshape(NB, BS, 3)
+    blo, bhi = B3.min(1), B3.max(1)
+    md = np.full((NB, BS), np.inf, np.float32)
+    key = np.full(NB, np.inf, np.float32)          # exact max (clean) or upper bound (dirty)
+    pstar = B3[:, 0, :].copy(); pidx = np.zeros(NB, np.int64)
+    dirty = np.zeros(NB, bool)
+    pend = [[] for _ in range(NB)]
+    nfl = 0; nap = 0; second = 0; fl_late = 0
+    picks = [0]
+    tau = 0.0
+    s = P[order[0]] if False else P[samples[0]]
+    K = len(samples)
+    def flush(j):
+        nonlocal nfl, nap
+        for t in pend[j]:
+            md[j] = np.minimum(md[j], ((B3[j] - t) ** 2).sum(1))
+        nap += len(pend[j]); pend[j] = []; dirty[j] = False
+        i = int(np.argmax(md[j])); key[j] = md[j, i]; pstar[j] = B3[j, i]; pidx[j] = i
+        nfl += 1
+    for k in range(K - 1):
+        s = P[samples[k]]
+        q = np.clip(s, blo, bhi); lb = ((s - q) ** 2).sum(1)
+        aff = np.nonzero(lb < key)[0]
+        far = np.where(np.abs(s - blo) >= np.abs(s - bhi), blo, bhi)
+        ubs = ((s - far) ** 2).sum(1)
+        hit = ((pstar - s) ** 2).sum(1) < key
+        before = nfl
+        for j in aff:
+            pend[j].append(s)
+            if mode == 'ub' or dirty[j] or hit[j]:
+                dirty[j] = True
+                key[j] = min(key[j], ubs[j])
+        for j in aff:
+            if (dirty[j] and key[j] >= tau) or len(pend[j]) >= PEND + (0 if dirty[j] else 0):
+                if len(pend[j]) >= PEND or dirty[j]:
+                    flush(j)
+        # pick among clean buckets
+        while True:
+            clean = ~dirty
+            v = key[clean].max() if clean.any() else -1.0
+            if v >= tau or not dirty.any():
+                break
+            tau = v; second += 1
+            for j in np.nonzero(dirty & (key >= tau))[0]:
+                flush(j)
+        if k >= 256: fl_late += nfl - before
+        tau = ALPHA * v
+    print(f"{tag:34s} flushes/round: all {nfl / (K - 1):6.2f}  late {fl_late / (K - 1 - 256):6.2f}   samples/flush {nap / max(nfl, 1):.2f}   second iterations {second}")
+
+
+if __name__ == '__main__':
+    o = np.argsort(h4, kind='stable')
+    simulate_lazy(P, o, samples, 3, 'ub', tag='deferred, dirty at once (kernel)')
+    simulate_lazy(P, o, samples, 3, 'pstar+ub', tag='deferred, clean until p* is hit')
+    simulate_lazy(P, o, samples, 8, 'pstar+ub', tag='same, 8-entry lists')

@@ -243,7 +243,7 @@ def simulate_lazy(P, order, samples, PEND, mode, ALPHA=0.95, BS=64, tag=''):
                 flush(j)
         if k >= 256: fl_late += nfl - before
         tau = ALPHA * v
-    print(f"{tag:34s} flushes/round: all {nfl / (K - 1):6.2f}  late {fl_late / (K - 1 - 256):6.2f}   samples/flush {nap / max(nfl, 1):.2f}   second iterations {second}")
+    print(f"{tag:34s} flushes/round: all {nfl / (K - 1):6.2f}  first 256 {(nfl - fl_late) / 256:6.2f}  late {fl_late / (K - 1 - 256):6.2f}   samples/flush {nap / max(nfl, 1):.2f}   second iterations {second}")
 
 
 if __name__ == '__main__':
@@ -251,3 +251,7 @@ if __name__ == '__main__':
     simulate_lazy(P, o, samples, 3, 'ub', tag='deferred, dirty at once (kernel)')
     simulate_lazy(P, o, samples, 3, 'pstar+ub', tag='deferred, clean until p* is hit')
     simulate_lazy(P, o, samples, 8, 'pstar+ub', tag='same, 8-entry lists')
+    for pd in (4, 5, 6, 7):
+        simulate_lazy(P, o, samples, pd, 'ub', tag=f'kernel scheme, {pd}-entry lists')
+    for al in (0.9, 0.85, 0.8):
+        simulate_lazy(P, o, samples, 7, 'ub', ALPHA=al, tag=f'kernel scheme, 7 entries, alpha {al}')

@@ -37,7 +37,11 @@ static inline DevParams pcp_to_dev(const pcp_params* p)
     DevParams d;
     d.dfx = p->depth.fx; d.dfy = p->depth.fy; d.dcx = p->depth.cx; d.dcy = p->depth.cy;
     d.rdfx = pcp_safe_recip(d.dfx); d.rdfy = pcp_safe_recip(d.dfy);
-    if (d.rdfx == 0.0 || d.rdfy == 0.0) d.rdfx = d.rdfy = 0.0;
+    // the principal point must be tame too (zero, or a mid-range number): pcp_quot_valid() relies on |u - cx| being
+    // either zero or far from the denormals
+    const bool tame_c = (d.dcx == 0.0 || pcp_safe_recip(d.dcx) != 0.0) && (d.dcy == 0.0 || pcp_safe_recip(d.dcy) != 0.0) &&
+                        (d.dcx < 0x1p100 && d.dcx > -0x1p100) && (d.dcy < 0x1p100 && d.dcy > -0x1p100);
+    if (d.rdfx == 0.0 || d.rdfy == 0.0 || !tame_c) d.rdfx = d.rdfy = 0.0;
     d.cfx = p->color.fx; d.cfy = p->color.fy; d.ccx = p->color.cx; d.ccy = p->color.cy;
     for (int i = 0; i < 12; ++i) { d.T[i] = p->T_d2c[i]; d.E[i] = p->ext[i]; }
     for (int i = 0; i < 3; ++i) { d.lo[i] = p->ws_lo[i]; d.hi[i] = p->ws_hi[i]; }
@@ -81,6 +85,22 @@ __device__ __forceinline__ double pcp_quot(double n, double d, double r, bool& b
     const bool zero = n == 0.0;
     bad = bad || !(ex - 523u < 1000u || zero);                            // 2^-500 <= |q| < 2^500, or an exact zero
     return zero ? q0 : q;
+}
+
+// The same quotient without the range check, for numerators that are KNOWN to be tame: n = (u - c) * z with an
+// integer pixel coordinate u < 2^31, a principal point c that is zero or mid-range (pcp_to_dev), and a depth z that
+// passed the float range test z_min < z < z_max, i.e. a FINITE float (zero or |z| in [2^-149, 2^128)).  Then |n| is zero
+// or in [2^-401, 2^229], every intermediate of the two residual steps is a normal number, the FMA residuals are exact
+// and Markstein's argument goes through; for any other z (NaN, infinite — the pixel fails the range test and its
+// coordinates are never looked at) the value is unspecified.  A zero numerator may lose the sign of its zero, which no
+// comparison can see.  Five FP64 instructions.
+__device__ __forceinline__ double pcp_quot_valid(double n, double d, double r)
+{
+    const double q0 = n * r;
+    double e = fma(-q0, d, n);
+    const double q1 = fma(e, r, q0);
+    e = fma(-q1, d, n);
+    return fma(e, r, q1);
 }
 
 // ---- wave / block primitives (64-wide wavefronts) ---------------------------------------

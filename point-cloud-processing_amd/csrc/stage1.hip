@@ -179,7 +179,7 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
     const int dv64 = 64 / W, du64 = 64 - dv64 * W;                    // 64 = dv64*W + du64 (scalar)
     // Phase by phase over the wave's four rounds instead of pixel by pixel: each phase needs only a few of the ~40
     // FP64 parameters, so they stay in scalar registers instead of being re-fetched for every round.
-    bool ok[4], bad = false;
+    bool ok[4];
     float dep[4];
     int ppu[4], ppv[4];
 #pragma unroll
@@ -192,12 +192,14 @@ k1_flags(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int H
         const float d = i < HW ? dframe[i] : 0.0f;                    // 0 fails the range test below
         const double z = (double)d;
         dep[r] = d; ppu[r] = pu; ppv[r] = pv;
-        cam[r][0] = pcp_quot(((double)pu - P.dcx) * z, P.dfx, P.rdfx, bad);     // XPC:62, exact (see pcp_quot)
-        cam[r][1] = pcp_quot(((double)pv - P.dcy) * z, P.dfy, P.rdfy, bad);     // XPC:63
+        // only pixels that pass the range test below are ever looked at, and for those the numerators are tame:
+        // the exact quotient without its range check (pcp_quot_valid)
+        cam[r][0] = pcp_quot_valid(((double)pu - P.dcx) * z, P.dfx, P.rdfx);    // XPC:62, exact
+        cam[r][1] = pcp_quot_valid(((double)pv - P.dcy) * z, P.dfy, P.rdfy);    // XPC:63
         cam[r][2] = z;
         ok[r] = (i < HW) & (d > P.z_min) & (d < P.z_max);             // XPC:109 (f32 compares)
     }
-    if (__any(bad) || P.rdfx == 0.0) {                                // wave-uniform: non-finite / extreme values, odd fx
+    if (P.rdfx == 0.0) {                                              // launch-uniform: odd intrinsics, plain divisions
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double z = (double)dep[r];

@@ -352,6 +352,8 @@ __global__ void pcp_csr_offsets(const long long* __restrict__ offsets, int B,
 // is computed: without rgb32 the colour-frame projection (more than half of the FP64 work and a scattered byte
 // gather) is skipped altogether — the pipeline then fetches the colours of the K sampled points only
 // (k1_gather_pixels below).
+#define K1_SC_TILES 4          // tiles per workgroup: one barrier and four independent depth loads per thread instead of
+                               // two barriers and one dependent load per tile (the pass is latency-, not bandwidth-bound)
 template <bool TFMA>
 __global__ void __launch_bounds__(256)
 k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int HW, int W, int Hc,
@@ -360,58 +362,86 @@ k1_scatter(const float* __restrict__ depth, const uint8_t* __restrict__ rgb, int
            double* xyz_cam64, double* xyz64, float* xyz32, float* rgb32, int32_t* pix,
            long long cap, int* overflow, int b_first, int b_stride)
 {
-    __shared__ unsigned long long m[PCP_TILE_WORDS];
-    __shared__ int pre[PCP_TILE_WORDS + 1];
-    const int b = b_first + blockIdx.y * b_stride, tile = blockIdx.x;
-    if (threadIdx.x < PCP_TILE_WORDS)
-        m[threadIdx.x] = masks[((size_t)b * tiles + tile) * PCP_TILE_WORDS + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int w = 0; w < PCP_TILE_WORDS; ++w) { pre[w] = acc; acc += __popcll(m[w]); }
-        pre[PCP_TILE_WORDS] = acc;
+    __shared__ unsigned long long m[K1_SC_TILES][PCP_TILE_WORDS];
+    __shared__ int pre[K1_SC_TILES][PCP_TILE_WORDS + 1];
+    const int b = b_first + blockIdx.y * b_stride, tile0 = blockIdx.x * K1_SC_TILES;
+    if (threadIdx.x < K1_SC_TILES * PCP_TILE_WORDS) {
+        // thread (t, w) fetches ballot word w of tile t; the sixteen lanes of a tile scan their popcounts among themselves
+        const int t = threadIdx.x / PCP_TILE_WORDS, w = threadIdx.x % PCP_TILE_WORDS;
+        const unsigned long long v = tile0 + t < tiles ? masks[((size_t)b * tiles + tile0 + t) * PCP_TILE_WORDS + w] : 0ull;
+        m[t][w] = v;
+        int incl = __popcll(v);
+#pragma unroll
+        for (int d = 1; d < PCP_TILE_WORDS; d <<= 1) {
+            const int x = __shfl_up(incl, d, PCP_TILE_WORDS);
+            if (w >= d) incl += x;
+        }
+        pre[t][w + 1] = incl;
+        if (w == 0) pre[t][0] = 0;
     }
     __syncthreads();
-    const int n = pre[PCP_TILE_WORDS];
-    if (n == 0) return;
-    const long long base = offsets[b] + tile_off[(size_t)b * tiles + tile];
+    int n[K1_SC_TILES], nmax = 0;
+    long long base[K1_SC_TILES];
+#pragma unroll
+    for (int t = 0; t < K1_SC_TILES; ++t) {
+        n[t] = pre[t][PCP_TILE_WORDS];
+        nmax = n[t] > nmax ? n[t] : nmax;
+        base[t] = n[t] ? offsets[b] + tile_off[(size_t)b * tiles + tile0 + t] : 0;
+    }
+    if (nmax == 0) return;
     const float* dframe = depth + (size_t)b * HW;
     const uint8_t* img = rgb ? rgb + (size_t)b * Hc * Wc * 3 : nullptr;
     const float invW = 1.0f / (float)W;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        int w = 0;
+    for (int j = threadIdx.x; j < nmax; j += blockDim.x) {
+        int pi[K1_SC_TILES];
+        float dep[K1_SC_TILES];
 #pragma unroll
-        for (int s = 8; s >= 1; s >>= 1)
-            if (pre[w + s] <= j) w += s;            // largest w with pre[w] <= j
-        const int bit = pcp_select_bit(m[w], j - pre[w]);
-        const int i = tile * PCP_TILE + w * 64 + bit;
-        const long long row = base + j;
-        if (row >= cap) { if (overflow) *overflow = 1; continue; }
-        int pv, pu;
-        pcp_divmod(i, W, invW, &pv, &pu);
-        const double z = (double)dframe[i];
-        double cam[3];
-        bool bad = false;
-        cam[0] = pcp_quot(((double)pu - P.dcx) * z, P.dfx, P.rdfx, bad);        // XPC:62 multiply, then divide (exact)
-        cam[1] = pcp_quot(((double)pv - P.dcy) * z, P.dfy, P.rdfy, bad);        // XPC:63
-        cam[2] = z;
-        if (__any(bad) || P.rdfx == 0.0) {                            // practically never: extreme values, odd fx
-            cam[0] = (((double)pu - P.dcx) * z) / P.dfx;
-            cam[1] = (((double)pv - P.dcy) * z) / P.dfy;
+        for (int t = 0; t < K1_SC_TILES; ++t) {                       // the four loads go out together
+            pi[t] = -1;
+            dep[t] = 0.f;
+            if (j < n[t]) {
+                int w = 0;
+#pragma unroll
+                for (int s = 8; s >= 1; s >>= 1)
+                    if (pre[t][w + s] <= j) w += s;                   // largest w with pre[w] <= j
+                const int bit = pcp_select_bit(m[t][w], j - pre[t][w]);
+                pi[t] = (tile0 + t) * PCP_TILE + w * 64 + bit;
+                dep[t] = dframe[pi[t]];
+            }
         }
-        if (xyz_cam64) { xyz_cam64[3 * row] = cam[0]; xyz_cam64[3 * row + 1] = cam[1]; xyz_cam64[3 * row + 2] = cam[2]; }
-        if (xyz64 || xyz32) {
-            double g[3];
-            rigid3(P.E, TFMA, cam[0], cam[1], cam[2], g);             // XPC:119
-            if (xyz64) { xyz64[3 * row] = g[0]; xyz64[3 * row + 1] = g[1]; xyz64[3 * row + 2] = g[2]; }
-            if (xyz32) { xyz32[3 * row] = (float)g[0]; xyz32[3 * row + 1] = (float)g[1]; xyz32[3 * row + 2] = (float)g[2]; }   // DP3:10
+#pragma unroll
+        for (int t = 0; t < K1_SC_TILES; ++t) {
+            const int i = pi[t];
+            const long long row = base[t] + j;
+            const bool live = i >= 0 && row < cap;
+            if (i >= 0 && row >= cap && overflow) *overflow = 1;
+            int pv, pu;
+            pcp_divmod(i < 0 ? 0 : i, W, invW, &pv, &pu);
+            const double z = (double)dep[t];
+            double cam[3];
+            bool bad = false;
+            cam[0] = pcp_quot(((double)pu - P.dcx) * z, P.dfx, P.rdfx, bad);    // XPC:62 multiply, then divide (exact)
+            cam[1] = pcp_quot(((double)pv - P.dcy) * z, P.dfy, P.rdfy, bad);    // XPC:63
+            cam[2] = z;
+            if (__any(bad && live) || P.rdfx == 0.0) {                // practically never: extreme values, odd fx
+                cam[0] = (((double)pu - P.dcx) * z) / P.dfx;
+                cam[1] = (((double)pv - P.dcy) * z) / P.dfy;
+            }
+            if (!live) continue;
+            if (xyz_cam64) { xyz_cam64[3 * row] = cam[0]; xyz_cam64[3 * row + 1] = cam[1]; xyz_cam64[3 * row + 2] = cam[2]; }
+            if (xyz64 || xyz32) {
+                double g[3];
+                rigid3(P.E, TFMA, cam[0], cam[1], cam[2], g);         // XPC:119
+                if (xyz64) { xyz64[3 * row] = g[0]; xyz64[3 * row + 1] = g[1]; xyz64[3 * row + 2] = g[2]; }
+                if (xyz32) { xyz32[3 * row] = (float)g[0]; xyz32[3 * row + 1] = (float)g[1]; xyz32[3 * row + 2] = (float)g[2]; }   // DP3:10
+            }
+            if (rgb32) {
+                float col[3];
+                align_math<true>(P, cam, img, Hc, Wc, col);           // XPC:66-78 (the mask already holds proj)
+                rgb32[3 * row] = col[0]; rgb32[3 * row + 1] = col[1]; rgb32[3 * row + 2] = col[2];
+            }
+            if (pix) pix[row] = i;
         }
-        if (rgb32) {
-            float col[3];
-            align_math<true>(P, cam, img, Hc, Wc, col);               // XPC:66-78 (the mask already holds proj)
-            rgb32[3 * row] = col[0]; rgb32[3 * row + 1] = col[1]; rgb32[3 * row + 2] = col[2];
-        }
-        if (pix) pix[row] = i;
     }
 }
 
@@ -537,8 +567,9 @@ static int backproject_align_crop_impl(const float* depth, const uint8_t* rgb, i
     }
     hipLaunchKernelGGL(pcp_scan_tiles, dim3(B), dim3(256), 0, st, tile_cnt, tiles, frame_cnt);
     hipLaunchKernelGGL(pcp_scan_frames, dim3(1), dim3(256), 0, st, frame_cnt, B, (long long*)offsets);
+    const dim3 sgrid((tiles + K1_SC_TILES - 1) / K1_SC_TILES, F);
     for (int c = 0; c < C; ++c)
-        hipLaunchKernelGGL(cams[c].transform_fma ? k1_scatter<true> : k1_scatter<false>, grid, dim3(256), 0, st, depth, rgb,
+        hipLaunchKernelGGL(cams[c].transform_fma ? k1_scatter<true> : k1_scatter<false>, sgrid, dim3(256), 0, st, depth, rgb,
                            HW, W, Hc, Wc, pcp_to_dev(cams + c), masks, tile_cnt, (const long long*)offsets, tiles,
                            xyz_cam64, xyz64, xyz32, rgb32, pix, (long long)cap, overflow, c, C);
     if (fused_offsets)

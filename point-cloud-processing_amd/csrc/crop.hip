@@ -113,7 +113,7 @@ extern "C" int pcp_crop_compact(const double* xyz, const double* rgb, int64_t M1
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_crop_workspace_bytes(M1)) return PCP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (M1 == 0) {
-        PCP_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int64_t), st));
+        PCP_FILL_TRY(count, 0u, 2, st);
         return PCP_OK;
     }
     const long long tiles = (M1 + PCP_TILE - 1) / PCP_TILE;
@@ -144,7 +144,7 @@ extern "C" int pcp_crop_compact_batched(const double* xyz, const double* rgb, co
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_crop_workspace_bytes(total)) return PCP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (total == 0 || B == 0) {
-        PCP_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(B + 1), st));
+        PCP_FILL_TRY(out_offsets, 0u, 2 * (size_t)(B + 1), st);
         return PCP_OK;
     }
     const long long tiles = (total + PCP_TILE - 1) / PCP_TILE;

@@ -1152,7 +1152,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_fps_workspace_bytes(B, total_pts, max_pts, K, algo))
         return PCP_ERR_WORKSPACE;
-    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || K == 0) return PCP_OK;
     FpsCall c;
     c.xyz = xyz; c.offsets = (const long long*)offsets; c.B = B; c.K = K; c.idx = (long long*)idx; c.out_xyz = out_xyz;

@@ -64,6 +64,24 @@ static inline int pcp_launch_status()
 
 static inline size_t pcp_align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// Flags, counters and small tables are cleared by a kernel of the library's own, not by hipMemsetAsync: recorded into a
+// HIP graph, a memset node in the middle of the graph replayed with a wrong fill value from the second replay on
+// (ROCm 7.2; the first node of the graph was fine) — tests/test_gpu_graph.py caught the FPS overflow flag coming back
+// as the low bits of a pointer.  A kernel node has no such surprise, and the cost is the same launch.
+static __global__ void pcp_fill_u32_k(unsigned int* __restrict__ p, unsigned int v, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+static inline int pcp_fill_u32(void* p, unsigned int v, size_t n_words, hipStream_t st)
+{
+    if (n_words == 0) return PCP_OK;
+    hipLaunchKernelGGL(pcp_fill_u32_k, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, (unsigned int*)p, v, n_words);
+    return hipGetLastError() == hipSuccess ? PCP_OK : PCP_ERR_LAUNCH;
+}
+#define PCP_FILL_TRY(p, v, n_words, st) do { if (pcp_fill_u32((p), (v), (n_words), (st)) != PCP_OK) return PCP_ERR_LAUNCH; } while (0)
+
 // ---- exact FP64 division by a launch constant ------------------------------------------------------
 // n / d, correctly rounded — bit for bit the IEEE division the reference's numpy expression performs — given
 // r = RN(1/d), d a mid-range number (pcp_safe_recip).  q0 = RN(n*r) is within a few ulp; one residual step

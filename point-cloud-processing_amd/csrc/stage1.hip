@@ -552,10 +552,10 @@ static int backproject_align_crop_impl(const float* depth, const uint8_t* rgb, i
     int* tile_cnt = (int*)w;
     w += pcp_align256((size_t)B * tiles * 4);
     long long* frame_cnt = (long long*)w;
-    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0) {
-        PCP_HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int64_t), st));
-        if (fused_offsets) PCP_HIP_TRY(hipMemsetAsync(fused_offsets, 0, sizeof(int64_t), st));
+        PCP_FILL_TRY(offsets, 0u, 2, st);
+        if (fused_offsets) PCP_FILL_TRY(fused_offsets, 0u, 2, st);
         return PCP_OK;
     }
     dim3 grid(tiles, F);

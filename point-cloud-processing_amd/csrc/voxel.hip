@@ -323,9 +323,9 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
     if (cap_pts > 0 && !xyz) return PCP_ERR_INVALID_ARG;
     if (out_rgb32 && !rgb) return PCP_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (overflow) PCP_HIP_TRY(hipMemsetAsync(overflow, 0, sizeof(int32_t), st));
+    if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || cap_pts == 0) {
-        PCP_HIP_TRY(hipMemsetAsync(out_offsets, 0, sizeof(int64_t) * (size_t)(B + 1), st));
+        PCP_FILL_TRY(out_offsets, 0u, 2 * (size_t)(B + 1), st);
         return PCP_OK;
     }
     const VoxLayout L = vox_layout(B, cap_pts);
@@ -343,7 +343,7 @@ extern "C" int pcp_voxel_downsample(const double* xyz, const float* rgb, const i
     const unsigned nblk = (unsigned)((cap_pts + 255) / 256);
     const int tiles = (int)((cap_pts + PCP_TILE - 1) / PCP_TILE);
 
-    PCP_HIP_TRY(hipMemsetAsync(minb, 0xFF, (size_t)B * 3 * 8, st));
+    PCP_FILL_TRY(minb, 0xFFFFFFFFu, (size_t)B * 6, st);
     hipLaunchKernelGGL(vox_minbound, dim3((nblk + VOX_MB_ITERS - 1) / VOX_MB_ITERS), dim3(256), 0, st, xyz, off, B, minb);
     {
         const int rc = vox_sorted_keys(xyz, off, B, cap_pts, minb, voxel_size, max_extent, keys_in, keys_out, vals_in,

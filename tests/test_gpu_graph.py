@@ -44,11 +44,14 @@ def test_frame_pipeline_records_into_a_hip_graph_and_replays():
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         pipe.run(depth, rgb)
-    for d, c, ref in ((d0, c0, ref0), (d1, c1, ref1), (d0, c0, ref0)):
+    for it, (d, c, ref) in enumerate(((d0, c0, ref0), (d1, c1, ref1), (d0, c0, ref0))):
         depth.copy_(torch.from_numpy(d)); rgb.copy_(torch.from_numpy(c))
         for t in (pipe.fps.xyz, pipe.rgb_out, pipe.fps.idx):
             t.fill_(-7)                                    # stale outputs must not pass
         g.replay()
+        torch.cuda.synchronize()
+        flags = (int(pipe.stage1.overflow[0]), int(pipe.fps.overflow[0]))
+        assert flags == (0, 0), f"replay {it}: overflow flags {flags}, offsets {pipe.stage1.offsets.tolist()}"
         got = snapshot()
         for a, b in zip(got, ref):
             assert torch.equal(a, b)

@@ -111,6 +111,43 @@ def test_fused_crop_matches_oracle_and_order():
         np.testing.assert_array_equal(np.nonzero(full["mask"])[0][keep], ref["pix"])
 
 
+@pytest.mark.parametrize("dintr", [
+    dict(fx=87.3, fy=91.1, cx=32.0, cy=24.0),                       # integer principal point: zero numerators on a column / row
+    dict(fx=87.3, fy=91.1, cx=0.0, cy=0.0),
+    dict(fx=87.3, fy=91.1, cx=1e-310, cy=31.7),                     # denormal principal point: library must divide the plain way
+    dict(fx=87.3, fy=91.1, cx=32.3, cy=3e120),                      # huge principal point: plain divisions again
+    dict(fx=2.5e-250, fy=91.1, cx=32.3, cy=24.6),                   # focal length outside the reciprocal's safe range
+    dict(fx=-87.3, fy=91.1, cx=32.3, cy=24.6),                      # negative focal length (mirrored image)
+    dict(fx=87.3 * (1 + 2.0 ** -52), fy=91.1 * (1 - 2.0 ** -53), cx=31.999999999999996, cy=24.000000000000004),
+])
+def test_unusual_intrinsics_keep_the_exact_quotients(dintr):
+    """The deprojection quotients go through a reciprocal + FMA residual steps when the intrinsics are tame and through true
+    divisions otherwise (pcp_to_dev decides per launch): both must equal the reference's numpy division bit for bit."""
+    rng = np.random.default_rng(11)
+    H, W = 48, 64
+    depth = (rng.integers(1, 4000, (2, H, W)).astype(np.float32) / 1000).astype(np.float32)
+    depth[0, ::7, ::5] = 0.0
+    depth[1, 3, :] = np.float32(1e-40)                              # float denormals pass z > 0 when z_min allows it
+    rgb = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    cintr = dict(fx=90.0, fy=90.0, cx=W / 2, cy=H / 2)
+    for crop in (False, True):
+        p = _ffi.make_params(dintr, cintr, apply_crop=crop)
+        po = cbind.make_params(dintr, cintr, apply_crop=int(crop))
+        p.z_min = po.z_min = 0.0
+        s1 = ops.Stage1(2, H, W, DEV, want=("xyz_cam64", "xyz64", "pix"))
+        with np.errstate(all="ignore"):
+            out, off = s1.run(dev(depth), dev(rgb), p)
+            off = off.cpu().numpy()
+            for b in range(2):
+                ref = cbind.backproject_align_crop(depth[b], rgb[b], po)
+                sl = slice(off[b], off[b + 1])
+                np.testing.assert_array_equal(out["pix"][sl].cpu().numpy(), ref["pix"])
+                np.testing.assert_array_equal(out["xyz64"][sl].cpu().numpy(), ref["xyz64"])
+                full = R.stage1_frame(depth[b], rgb[b], dintr, cintr)     # the numpy expression itself, XPC:58-64
+                cam = full["pts_cam"][ref["pix"]]
+                np.testing.assert_array_equal(out["xyz_cam64"][sl].cpu().numpy(), cam)
+
+
 def test_stage1_capacity_overflow_flag_and_ragged_size():
     # H*W not a multiple of 64 / 1024, tiny capacity
     rng = np.random.default_rng(4)

@@ -200,6 +200,41 @@ def test_fps_single_point_and_random_agreement():
         prev = d
 
 
+def _fps_torch_form(points, K):
+    """pytorch3d's pure-python fallback (`sample_farthest_points_naive`, restated from its published form — pytorch3d
+    itself is not installed) evaluated with torch's own CPU kernels: closest_dists starts at +inf, the selected index at 0
+    (random_start_point=False); every round takes `((points[sel] - points) ** 2).sum(-1)`, `torch.min` with the running
+    distances and `torch.argmax` of the result.  float32 throughout (DP3:10), -1 padding beyond the cloud's length."""
+    import torch
+    pts = torch.from_numpy(np.asarray(points)).float()
+    n = pts.shape[0]
+    idx = [-1] * K
+    closest = pts.new_full((n,), float("inf"))
+    sel = 0
+    for i in range(min(K, n)):
+        idx[i] = sel
+        d = ((pts[sel, :] - pts) ** 2).sum(-1)
+        closest = torch.min(d, closest)
+        sel = int(torch.argmax(closest))
+    return np.asarray(idx, dtype=np.int64)
+
+
+def test_fps_three_independent_forms_agree():
+    """numpy arg-max form, the plain C loops and the torch-operator form of pytorch3d's naive reference pick the same
+    indices — on random volumes, a lattice full of exact ties, duplicates and a cloud shorter than K."""
+    rng = np.random.default_rng(15)
+    g = np.stack(np.meshgrid(*[np.arange(7)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    cases = [(rng.uniform(-1, 1, (1500, 3)), 120), (rng.permutation(g) * 0.25, 200),
+             (np.repeat(rng.uniform(0, 1, (40, 3)), 5, axis=0), 60), (rng.uniform(0, 1, (9, 3)), 16),
+             (rng.standard_normal((800, 3)) * np.array([1.0, 0.5, 0.01]), 300)]
+    for pts, K in cases:
+        _, i_np = R.fps(pts, K)
+        _, i_c = cbind.fps(pts, K, 0)
+        i_t = _fps_torch_form(pts, K)
+        np.testing.assert_array_equal(i_np, i_c)
+        np.testing.assert_array_equal(i_t, i_c)
+
+
 def test_fps_fma_mode_close_to_nofma():
     rng = np.random.default_rng(6)
     pts = rng.uniform(-1, 1, (2000, 3))

@@ -55,3 +55,34 @@ def test_frame_pipeline_records_into_a_hip_graph_and_replays():
         got = snapshot()
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
+
+
+def test_static_entry_point_records_into_a_hip_graph():
+    """pcp_fps_batched_static is meant for callers that cannot allocate — code under graph capture first of all: record it,
+    replay it on two inputs, compare with pcp_fps_batched."""
+    import ctypes as C
+    L = _ffi.load_library()
+    rng = np.random.default_rng(3)
+    M, K = 30000, 200
+    clouds = [rng.uniform(-1, 1, (M, 3)).astype(np.float32), rng.normal(0, 0.3, (M, 3)).astype(np.float32)]
+    xyz = torch.from_numpy(clouds[0]).cuda()
+    off = torch.tensor([0, M], dtype=torch.int64, device="cuda")
+    idx = torch.full((1, K), -7, dtype=torch.int64, device="cuda")
+    out = torch.zeros((1, K, 3), dtype=torch.float32, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = L.pcp_fps_batched_static(p(xyz), p(off), 1, M, M, K, 1, 0, p(idx), p(out), p(flag),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    ref = ops.Fps(1, M, M, K, "cuda", 1, 0)
+    for c in (clouds[1], clouds[0], clouds[1]):
+        xyz.copy_(torch.from_numpy(c))
+        idx.fill_(-7); flag.fill_(9)
+        g.replay()
+        ref.run(xyz, off)
+        torch.cuda.synchronize()
+        assert int(flag) == 0
+        assert torch.equal(idx, ref.idx) and torch.equal(out, ref.xyz)

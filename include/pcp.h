@@ -278,6 +278,20 @@ int pcp_gather_rgb_pixels(const float* depth, const uint8_t* rgb, int B, int H, 
                           const int64_t* idx, int K, int compat_neg_index, float* out, void* stream);
 
 /*
+ * WHERE the colour of every sampled point sits instead of the colour itself: the colour-image pixel
+ * v_idx * Wc + u_idx that align_colors looks up (XPC:73, 77), or -1 where it leaves the colour zero (the point
+ * is outside the colour image or too close, XPC:74-76) or the index does not exist.  The projection mask needs
+ * rgb.shape only (XPC:72-75) and colours are wanted for K points per frame (DP3:48), so a caller that keeps the
+ * decoded rgb images in HOST memory uploads depth alone (0.6 MB instead of 1.5 MB per 640x480 frame with u16
+ * depth; pass rgb = NULL and rgb32 = NULL to pcp_backproject_align_crop) and finishes on the host:
+ *     colour[b][k] = cpix[b][k] < 0 ? 0 : rgb_b[cpix[b][k]] / 255   (XPC:77; * 255 again for the CHK:141 rows)
+ * Arguments as pcp_gather_rgb_pixels (idx = -1 follows compat_neg_index the same way); cpix (B,K) i32.
+ */
+int pcp_sampled_color_pixels(const float* depth, int B, int H, int W, int Hc, int Wc, const pcp_params* p,
+                             const int32_t* pix, const int64_t* offsets, int64_t total_pts,
+                             const int64_t* idx, int K, int compat_neg_index, int32_t* cpix, void* stream);
+
+/*
  * (K,6) rows exactly as chunking_data.py:134-144 stacks them for the zarr
  * `data/point_cloud` array (CHK:195): [x, y, z, r*255, g*255, b*255] as f32.
  *   xyz (B,K,3) f32, rgb (B,K,3) f32 in [0,1] → out (B,K,6) f32

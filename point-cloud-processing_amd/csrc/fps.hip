@@ -190,6 +190,86 @@ __device__ __forceinline__ void wave_argmax_key_x(const unsigned long long (&k)[
     }
 }
 
+// Wave-uniform TOP TWO of the multiset union of one (a1 >= a2) pair per lane: a1 = the largest value, a2 = the second
+// largest (equal to a1 when the maximum occurs twice).  Same DPP butterfly as wave_umax_u32; every step merges two
+// disjoint lane sets, so the multiset semantics are exact.  Lanes a row-masked step leaves out read 0, the identity.
+__device__ __forceinline__ void wave_top2_u32(unsigned& a1, unsigned& a2)
+{
+#define PCP_TOP2_STEP(CTRL, RM)                                             \
+    {                                                                       \
+        const unsigned t1_ = dpp_u32<CTRL, RM>(a1), t2_ = dpp_u32<CTRL, RM>(a2); \
+        const unsigned lo_ = min(a1, t1_);                                  \
+        a1 = max(a1, t1_);                                                  \
+        a2 = max(max(a2, t2_), lo_);                                        \
+    }
+    PCP_TOP2_STEP(0xB1, 0xf)
+    PCP_TOP2_STEP(0x4E, 0xf)
+    PCP_TOP2_STEP(0x141, 0xf)
+    PCP_TOP2_STEP(0x140, 0xf)
+    PCP_TOP2_STEP(0x142, 0xA)
+    PCP_TOP2_STEP(0x143, 0xC)
+#undef PCP_TOP2_STEP
+    a1 = (unsigned)__builtin_amdgcn_readlane((int)a1, 63);
+    a2 = (unsigned)__builtin_amdgcn_readlane((int)a2, 63);
+}
+
+// G of them at once, chains interleaved (see wave_umax_u32_x)
+template <int G>
+__device__ __forceinline__ void wave_top2_u32_x(unsigned (&a1)[G], unsigned (&a2)[G])
+{
+#define PCP_TOP2_STEP(CTRL, RM)                                             \
+    {                                                                       \
+        unsigned t1_[G], t2_[G];                                            \
+        _Pragma("unroll") for (int u = 0; u < G; ++u) { t1_[u] = dpp_u32<CTRL, RM>(a1[u]); t2_[u] = dpp_u32<CTRL, RM>(a2[u]); } \
+        _Pragma("unroll") for (int u = 0; u < G; ++u) {                     \
+            const unsigned lo_ = min(a1[u], t1_[u]);                        \
+            a1[u] = max(a1[u], t1_[u]);                                     \
+            a2[u] = max(max(a2[u], t2_[u]), lo_);                           \
+        }                                                                   \
+    }
+    PCP_TOP2_STEP(0xB1, 0xf)
+    PCP_TOP2_STEP(0x4E, 0xf)
+    PCP_TOP2_STEP(0x141, 0xf)
+    PCP_TOP2_STEP(0x140, 0xf)
+    PCP_TOP2_STEP(0x142, 0xA)
+    PCP_TOP2_STEP(0x143, 0xC)
+#undef PCP_TOP2_STEP
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        a1[u] = (unsigned)__builtin_amdgcn_readlane((int)a1[u], 63);
+        a2[u] = (unsigned)__builtin_amdgcn_readlane((int)a2[u], 63);
+    }
+}
+
+// G wave arg-maxes at once that also return the RUNNER-UP VALUE of each key set (the largest value among the other
+// lanes' keys and the per-lane runner-up values r[]; equal to the top value on a tie).  Every key set must hold at
+// least one non-zero key.
+template <int G>
+__device__ __forceinline__ void wave_argmax2_key_x(const unsigned long long (&k)[G], const unsigned (&r)[G],
+                                                   unsigned long long (&wk)[G], unsigned (&ws)[G], int (&src)[G])
+{
+    unsigned m[G], m2[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) { m[u] = (unsigned)(k[u] >> 32); m2[u] = r[u]; }
+    wave_top2_u32_x<G>(m, m2);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const unsigned h = (unsigned)(k[u] >> 32), lo = (unsigned)k[u];
+        unsigned long long hit = __ballot(h == m[u]);
+        unsigned l;
+        if (__popcll(hit) == 1) {                              // wave-uniform, the common case
+            src[u] = __ffsll((long long)hit) - 1;
+            l = (unsigned)__builtin_amdgcn_readlane((int)lo, src[u]);
+        } else {
+            l = wave_umax_u32(h == m[u] ? lo : 0u);
+            hit = __ballot(h == m[u] && lo == l);
+            src[u] = __ffsll((long long)hit) - 1;
+        }
+        wk[u] = ((unsigned long long)m[u] << 32) | l;
+        ws[u] = m2[u];
+    }
+}
+
 // arg-max over the keys held by lanes 0..N-1 (N = 4, 8 or 16).  The reduction stays inside row 0 and the ballots
 // are masked to the low N lanes, so the other lanes may hold anything (no exec masking around the loads).
 template <int N>
@@ -711,10 +791,11 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
 template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
-    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 64;
+    // cell histogram | red | wave partial keys [2][NW] | their xyz [2][NW] | bucket arg-max xyz [T*CPL] | round picks [4] + count
+    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 4 * 16 + 16 + 64;
 }
 
-template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
+template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
@@ -757,11 +838,6 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     float4* S = pts4 + base;
     float* D = md + base;
 
-#ifdef PCP_FPS_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, tp0 = 0, tp1 = 0;
-    unsigned long long sA = 0, sB = 0, sR = 0, sW = 0, sC = 0, sPass = 0, sAct = 0, sMem = 0, sCmp = 0, sRed = 0, tc0 = 0;
-    STAMP(tp0);
-#endif
     fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
 #if defined(PCP_FPS_STOP_AFTER) && PCP_FPS_STOP_AFTER <= 3
     return;                                                      // tuning builds: time the prologue's phases
@@ -807,65 +883,302 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     }
     float sx = P[0], sy = P[1], sz = P[2];
     int last = 0;
-    // Wave-uniform arg-max over ALL buckets the wave owns (key, bucket).  Keys only ever decrease, so
-    // while that bucket is not touched it stays the wave's maximum and no reduction is needed.
+    // Wave-uniform arg-max over ALL buckets the wave owns (key, bucket), as the deferred rounds track it.
     unsigned long long wmax = __builtin_amdgcn_readfirstlane((int)(key[0] >> 32)) ? make_key(FLT_MAX, 0u) : 0ull;
     int wmax_j = wave;
-    STAMP(tp1);
+
+    // every owned slot's arg-max point starts as the first sample: round 0 then "hits" every bucket (distance 0)
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) bxyz[(s * 64 + lane) * NW + wave] = make_float4(sx, sy, sz, 0.f);
 
     // ---- rounds -------------------------------------------------------------------------------------
     int k0 = 0;
     if constexpr (!MULTI && CPL == 1) {
         static_assert(PCP_FPS_NCELL * 4 >= PCP_FPS_LAZY_MAX_ROUNDS * 16, "the sample table reuses the cell histogram");
         k0 = min(min(lazy_k, PCP_FPS_LAZY_MAX_ROUNDS), kn - 1);
+#ifndef PCP_NO_LAZY
         if (k0 > 0)                                             // workgroup-uniform
             fps_lazy_rounds<T, MODE, BH>(k0, M, NB, S, D, (float4*)cellcnt, pkey, pxyz, bxyz, irow, orow, tid, lane, wave,
                                      key[0], blo[0], bhi[0], sx, sy, sz, last, wmax, wmax_j);
+#endif
     }
-    for (int k = k0;; ++k) {
-        if (tid == 0) {
-            irow[k] = last;
-            if (orow) { orow[3 * k] = sx; orow[3 * k + 1] = sy; orow[3 * k + 2] = sz; }
+    if constexpr (!MP) {
+        // ONE PICK PER ROUND: the shape for batches that put more than one workgroup on a CU, where the rounds are bound by
+        // instruction issue and the leanest round wins (the multi-pick rounds below spend more instructions per pick).
+        for (int k = k0;; ++k) {
+            if (tid == 0) {
+                irow[k] = last;
+                if (orow) { orow[3 * k] = sx; orow[3 * k + 1] = sy; orow[3 * k + 2] = sz; }
+            }
+            if (k + 1 >= kn) break;
+            const int par = k & 1;
+            // bucket tests by the owning lanes
+            unsigned long long amask[CPL];
+    #pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                const float cmax = __uint_as_float((unsigned)(key[s] >> 32));
+                const float qx = __builtin_amdgcn_fmed3f(sx, blo[s][0], bhi[s][0]);   // clamp(s, box)
+                const float qy = __builtin_amdgcn_fmed3f(sy, blo[s][1], bhi[s][1]);
+                const float qz = __builtin_amdgcn_fmed3f(sz, blo[s][2], bhi[s][2]);
+                amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
+            }
+            // Running wave candidate (all wave-uniform): arg-max over the buckets this round leaves
+            // untouched — reduced while the first loads are in flight — then raised by every bucket the
+            // wave updates.  cand_j is the candidate's bucket: its xyz sits in bxyz[cand_j].
+            unsigned long long cand = wmax;
+            int cand_j = wmax_j;
+            bool need_idle = false;
+    #pragma unroll
+            for (int s = 0; s < CPL; ++s)                           // is the wave's top bucket about to change?
+                if (((wmax_j / NW) >> 6) == s && ((amask[s] >> ((wmax_j / NW) & 63)) & 1ull)) need_idle = true;
+            auto idle_argmax = [&]() {
+                if (!need_idle) return;                             // wave-uniform
+                unsigned long long kb = 0ull;
+                int sb = 0;
+    #pragma unroll
+                for (int s = 0; s < CPL; ++s) {
+                    const bool act = (amask[s] >> lane) & 1ull;
+                    if (!act && key[s] > kb) { kb = key[s]; sb = s; }
+                }
+                int src;
+                cand = wave_argmax_key(kb, &src);
+                cand_j = ((__builtin_amdgcn_readlane(sb, src) * 64 + src) * NW + wave);
+            };
+            // The wave streams its own active buckets, up to four in flight; the pass body is
+            // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
+            auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], unsigned long long& key_s, int s_idx, bool first) {
+                constexpr int G = decltype(GC)::value;
+                constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
+                int r0[G];
+    #pragma unroll
+                for (int u = 0; u < G; ++u)                         // BH > 1: BH consecutive slots are the parts of one bucket
+                    r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (u % BH) * 64;
+                unsigned long long bk[G];
+                float4 bp[G];
+                const int nchunks = MULTI ? chunks : 1;
+                for (int c = 0; c < nchunks; ++c) {
+                    float4 pt[G];
+                    float mm[G];
+    #pragma unroll
+                    for (int u = 0; u < G; ++u) {                   // unconditional loads: all in flight together
+                        if (FULL) {                                 // scalar base + lane: no per-lane address math
+                            pt[u] = (S + (r0[u] + c * 64))[lane];
+                            mm[u] = (D + (r0[u] + c * 64))[lane];
+                        } else {
+                            const int r = min(r0[u] + c * 64 + lane, M - 1);
+                            pt[u] = S[r];
+                            mm[u] = D[r];
+                        }
+                    }
+                    if (first && c == 0) idle_argmax();             // VALU work under the memory latency
+    #pragma unroll
+                    for (int u = 0; u < G; ++u)                     // keep hipcc from sinking a load into the update branch
+                        asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
+    #pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int r = r0[u] + c * 64 + lane;
+                        const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
+                        const bool live = FULL || r < M;
+                        if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
+                        const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
+                        if (!MULTI || c == 0 || kk > bk[u]) { bk[u] = kk; bp[u] = pt[u]; }
+                    }
+                }
+                unsigned long long wk[G];
+                int src[G];
+                wave_argmax_key_x<G>(bk, wk, src);
+                if constexpr (BH > 1 && G < BH) {
+                    // never called: a split bucket occupies BH slots
+                } else if constexpr (BH > 1) {
+    #pragma unroll
+                    for (int q = 0; q < G; q += BH) {               // the bucket's key is the largest of its parts' keys
+                        const int j = (s_idx * 64 + ol[q]) * NW + wave;
+                        int w = q;                                  // scalar
+                        unsigned long long wb = wk[q];
+    #pragma unroll
+                        for (int h = 1; h < BH; ++h)
+                            if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
+    #pragma unroll
+                        for (int h = 0; h < BH; ++h)
+                            if (w == q + h && lane == src[q + h]) bxyz[j] = bp[q + h];
+                        if (lane == ol[q]) key_s = wb;
+                        if (wb > cand) { cand = wb; cand_j = j; }
+                    }
+                } else {
+    #pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int j = (s_idx * 64 + ol[u]) * NW + wave;
+                        if (lane == src[u]) bxyz[j] = bp[u];
+                        if (lane == ol[u]) key_s = wk[u];
+                        if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
+                    }
+                }
+            };
+            bool first = true;
+            __builtin_amdgcn_s_setprio(3);                          // the streaming phase is the round's critical path
+    #pragma unroll
+            for (int s = 0; s < CPL; ++s) {
+                unsigned long long m = amask[s];
+                while (m) {                                         // wave-uniform
+                    int ol[4], n = 0;
+                    if constexpr (BH > 1) {                         // 4 / BH buckets per pass, BH slots each
+    #pragma unroll
+                        for (int u = 0; u < 4; u += BH) {
+                            if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + BH; }
+                            else ol[u] = ol[0];
+    #pragma unroll
+                            for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
+                        }
+                    } else {
+    #pragma unroll
+                        for (int u = 0; u < 4; ++u) {               // a fourth slot left over repeats slot 0: harmless
+                            if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                            else ol[u] = ol[0];
+                        }
+                    }
+                    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                    using I4 = std::integral_constant<int, 4>;
+                    // only the cloud's last bucket can be short of rows; it belongs to lane (NB-1)/NW % 64
+                    const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || (((NB - 1) / NW) >> 6) != s ||
+                                      !((amask[s] >> (((NB - 1) / NW) & 63)) & 1ull);
+                    if (full) {
+                        if (n == 1) run_pass(I1{}, std::true_type{}, ol, key[s], s, first);
+                        else if (n == 2) run_pass(I2{}, std::true_type{}, ol, key[s], s, first);
+                        else run_pass(I4{}, std::true_type{}, ol, key[s], s, first);
+                    } else {
+                        run_pass(I4{}, std::false_type{}, ol, key[s], s, first);
+                    }
+                    first = false;
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (first) idle_argmax();                               // nothing to stream this round
+            wmax = cand;                                            // = arg-max over all the wave's buckets again
+            wmax_j = cand_j;
+            // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
+            if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
+            // Workgroup barrier WITHOUT draining global stores: only LDS traffic (the partials) has to be
+            // visible to the other waves.  The min_d stores of this round are re-read by this wave alone
+            // (a bucket is streamed by its owning wave only), and same-wave accesses stay ordered, so
+            // waiting for their acknowledgements — which __syncthreads() does — is wasted serial time.
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                // every low lane fetches its wave's key AND xyz in one LDS round trip; the winner's xyz is then a
+                // readlane away instead of a second, dependent LDS read
+                const unsigned long long kk = pkey[par * NW + (lane & (NW - 1))];
+                const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
+                int src;
+                const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
+                last = wk ? (int)(~(unsigned)wk) : 0;
+                sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
+            }
         }
-        if (k + 1 >= kn) break;
-        const int par = k & 1;
+        return;
+    }
+    if (tid == 0) {
+        irow[k0] = last;
+        if (orow) { orow[3 * k0] = sx; orow[3 * k0 + 1] = sy; orow[3 * k0 + 2] = sz; }
+    }
+    int kd = k0 + 1;                                            // picks decided (and written) so far
+    if (kd >= kn) return;
+
+    // MULTI-PICK ROUNDS.  One round applies the n <= 4 newest samples to every bucket any of them could change
+    // (one pass over a bucket's rows for all of them), then certifies up to four further picks at once:
+    //   every wave publishes its best point (key, xyz) and `rub`, an upper bound of every OTHER min-distance it owns
+    //   (the second-largest value of the multiset {bucket top, bucket runner-up} over its buckets).  Let a1 > a2 > ...
+    //   be the wave tops in key order, from waves w1, w2, ...  a1 is the next pick, as ever.  a_i is certainly the
+    //   pick after a_(i-1) when for every earlier pick a_j of this round
+    //       rub(w_j) < value(a_i)             nothing else in an earlier winner's wave can overtake a_i,
+    //       !(dist2(a_j, a_i) < value(a_i))   applying a_j leaves a_i's min-distance as it is,
+    //       a_j is finite                     its own min-distance drops to 0 once it is applied,
+    //   and value(a_i) is strictly above every remaining wave top: all other points only lose min-distance, so a_i
+    //   stays the arg-max (ties on a value end the chain, the next round resolves them by index as a first pick).
+    // min() is exact and commutative, so applying a round's samples together leaves the same min-distances as
+    // applying them one by one; a bucket test against the older, larger bucket maximum only streams a superset.
+    // The picks are therefore the sequential ones, in order — with a third of the workgroup rounds on the bench
+    // clouds (tests/model_fps_multipick.py: 350 rounds for 1,023 picks).  One wave certifies the picks between two
+    // barriers instead of all sixteen doing it redundantly: the chain is ~4x longer than a single arg-max and
+    // sixteen copies of it would occupy every SIMD of the CU (and of the workgroup sharing it).
+    float4* sel = bxyz + NBMAX;                                          // [4] the round's picks {x,y,z,bits(idx)}
+    int* nselp = (int*)(sel + 4);                                        // their number
+    unsigned sec[CPL];                                                   // runner-up VALUE of the bucket (an upper bound is enough)
+#pragma unroll
+    for (int s = 0; s < CPL; ++s) sec[s] = (unsigned)(key[s] >> 32);     // unknown yet: as large as the top
+    float4 sm = make_float4(sx, sy, sz, 0.f);                            // lane i < n: sample i of the round (copy of sel[i])
+    int n = 1;
+    if (tid == 0) sel[0] = sm;
+    __syncthreads();
+    unsigned long long cand = 0ull;                                      // the wave's best point, its bucket, its rub
+    int cand_j = wave;
+    unsigned c2 = 0u;
+    bool cached = false;
+#ifdef PCP_FPS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, sT = 0, sS = 0, sP = 0, sB1 = 0, sK = 0, sB2 = 0, nR = 0, nPass = 0, nAct = 0;
+#endif
+    for (;;) {
         STAMP(t0);
-        // bucket tests by the owning lanes
+        // bucket tests by the owning lanes, against every sample of the round
         unsigned long long amask[CPL];
+        bool any = false;
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             const float cmax = __uint_as_float((unsigned)(key[s] >> 32));
-            const float qx = __builtin_amdgcn_fmed3f(sx, blo[s][0], bhi[s][0]);   // clamp(s, box)
-            const float qy = __builtin_amdgcn_fmed3f(sy, blo[s][1], bhi[s][1]);
-            const float qz = __builtin_amdgcn_fmed3f(sz, blo[s][2], bhi[s][2]);
-            amask[s] = __ballot(dist2<MODE>(sx, sy, sz, qx, qy, qz) < cmax);
-        }
-        STAMP(t1);
-        // Running wave candidate (all wave-uniform): arg-max over the buckets this round leaves
-        // untouched — reduced while the first loads are in flight — then raised by every bucket the
-        // wave updates.  cand_j is the candidate's bucket: its xyz sits in bxyz[cand_j].
-        unsigned long long cand = wmax;
-        int cand_j = wmax_j;
-        bool need_idle = false;
+            bool aff = false;
 #pragma unroll
-        for (int s = 0; s < CPL; ++s)                           // is the wave's top bucket about to change?
-            if (((wmax_j / NW) >> 6) == s && ((amask[s] >> ((wmax_j / NW) & 63)) & 1ull)) need_idle = true;
-        auto idle_argmax = [&]() {
-            if (!need_idle) return;                             // wave-uniform
+            for (int i = 0; i < 4; ++i) {
+                if (i < n) {                                             // wave-uniform
+                    const float ax = rl(sm.x, i), ay = rl(sm.y, i), az = rl(sm.z, i);
+                    const float qx = __builtin_amdgcn_fmed3f(ax, blo[s][0], bhi[s][0]);   // clamp(sample, box)
+                    const float qy = __builtin_amdgcn_fmed3f(ay, blo[s][1], bhi[s][1]);
+                    const float qz = __builtin_amdgcn_fmed3f(az, blo[s][2], bhi[s][2]);
+                    aff = aff || dist2<MODE>(ax, ay, az, qx, qy, qz) < cmax;
+                }
+            }
+            amask[s] = __ballot(aff);
+            any = any || amask[s] != 0ull;
+        }
+        // The wave's partial (cand, cand_j, c2) is rebuilt whenever one of its buckets changes: the untouched buckets
+        // are reduced while the first loads are in flight, every streamed bucket is merged in as it finishes.
+        const bool rebuild = any || !cached;
+        if (rebuild) { cand = 0ull; cand_j = wave; c2 = 0u; }
+        auto idle_top2 = [&]() {
             unsigned long long kb = 0ull;
+            unsigned v2 = 0u;
             int sb = 0;
 #pragma unroll
             for (int s = 0; s < CPL; ++s) {
                 const bool act = (amask[s] >> lane) & 1ull;
-                if (!act && key[s] > kb) { kb = key[s]; sb = s; }
+                if (!act) {
+                    if (key[s] > kb) { v2 = max(v2, max((unsigned)(kb >> 32), sec[s])); kb = key[s]; sb = s; }
+                    else v2 = max(v2, (unsigned)(key[s] >> 32));
+                }
             }
+            const unsigned h = (unsigned)(kb >> 32), lo = (unsigned)kb;
+            unsigned a1 = h, a2 = v2;
+            wave_top2_u32(a1, a2);
+            unsigned long long hit = __ballot(h == a1);
             int src;
-            cand = wave_argmax_key(kb, &src);
-            cand_j = ((__builtin_amdgcn_readlane(sb, src) * 64 + src) * NW + wave);
+            unsigned l;
+            if (__popcll(hit) == 1) {
+                src = __ffsll((long long)hit) - 1;
+                l = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+            } else {
+                l = wave_umax_u32(h == a1 ? lo : 0u);
+                hit = __ballot(h == a1 && lo == l);
+                src = __ffsll((long long)hit) - 1;
+            }
+            cand = ((unsigned long long)a1 << 32) | l;
+            cand_j = (__builtin_amdgcn_readlane(sb, src) * 64 + src) * NW + wave;
+            c2 = a2;
+        };
+        auto merge = [&](unsigned long long wk, unsigned ws, int j) {     // all wave-uniform
+            if (wk > cand) { c2 = max(c2, max((unsigned)(cand >> 32), ws)); cand = wk; cand_j = j; }
+            else c2 = max(c2, (unsigned)(wk >> 32));
         };
         // The wave streams its own active buckets, up to four in flight; the pass body is
         // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
-        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], unsigned long long& key_s, int s_idx, bool first) {
+        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], unsigned long long& key_s, unsigned& sec_s, int s_idx,
+                            bool first) {
             constexpr int G = decltype(GC)::value;
             constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
             int r0[G];
@@ -873,7 +1186,10 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             for (int u = 0; u < G; ++u)                         // BH > 1: BH consecutive slots are the parts of one bucket
                 r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (u % BH) * 64;
             unsigned long long bk[G];
+            unsigned bs[G];                                     // MULTI: the lane's runner-up value over the chunks
             float4 bp[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) bs[u] = 0u;
             const int nchunks = MULTI ? chunks : 1;
             for (int c = 0; c < nchunks; ++c) {
                 float4 pt[G];
@@ -889,70 +1205,99 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
                         mm[u] = D[r];
                     }
                 }
-                if (first && c == 0) idle_argmax();             // VALU work under the memory latency
+                // the round's samples come back from LDS as broadcast reads (every lane the same address): they arrive
+                // long before the rows do and are plain VGPR operands of the distance code, dead again before the arg-max
+                if (first && c == 0) idle_top2();               // VALU work under the memory latency
+                float sa[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float* sf = (const float*)(sel + (i < n ? i : 0));
+                    sa[i][0] = sf[0]; sa[i][1] = sf[1]; sa[i][2] = sf[2];
+                }
 #pragma unroll
                 for (int u = 0; u < G; ++u)                     // keep hipcc from sinking a load into the update branch
                     asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
-#ifdef PCP_FPS_STAMPS
-                { unsigned long long ta, tb; STAMP(ta); __builtin_amdgcn_s_waitcnt(0x0F70); STAMP(tb); sMem += tb - ta; STAMP(tc0); }
-#endif
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int r = r0[u] + c * 64 + lane;
-                    const float d = dist2<MODE>(sx, sy, sz, pt[u].x, pt[u].y, pt[u].z);
+                    float m = mm[u];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i < n)                              // fminf keeps m when d is NaN, like a `d < m` update
+                            m = fminf(m, dist2<MODE>(sa[i][0], sa[i][1], sa[i][2], pt[u].x, pt[u].y, pt[u].z));
+                    }
                     const bool live = FULL || r < M;
-                    if (live && d < mm[u]) { mm[u] = d; D[r] = d; }
-                    const unsigned long long kk = live ? make_key(mm[u], (unsigned)__float_as_int(pt[u].w)) : 0ull;
-                    if (!MULTI || c == 0 || kk > bk[u]) { bk[u] = kk; bp[u] = pt[u]; }
+                    if (live && m < mm[u]) D[r] = m;
+                    const unsigned long long kk = live ? make_key(m, (unsigned)__float_as_int(pt[u].w)) : 0ull;
+                    if (!MULTI || c == 0) { bk[u] = kk; bp[u] = pt[u]; }
+                    else if (kk > bk[u]) { bs[u] = max(bs[u], (unsigned)(bk[u] >> 32)); bk[u] = kk; bp[u] = pt[u]; }
+                    else bs[u] = max(bs[u], (unsigned)(kk >> 32));
                 }
             }
-#ifdef PCP_FPS_STAMPS
-            { unsigned long long tb; STAMP(tb); sCmp += tb - tc0; tc0 = tb; }
-#endif
             unsigned long long wk[G];
+            unsigned ws[G];
             int src[G];
-            wave_argmax_key_x<G>(bk, wk, src);
+            if constexpr (G == 4) {                             // two chains of two: fewer live registers than four at once
+                unsigned long long bk2[2], wk2[2];
+                unsigned bs2[2], ws2[2];
+                int src2[2];
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    bk2[0] = bk[g]; bk2[1] = bk[g + 1]; bs2[0] = bs[g]; bs2[1] = bs[g + 1];
+                    wave_argmax2_key_x<2>(bk2, bs2, wk2, ws2, src2);
+                    wk[g] = wk2[0]; wk[g + 1] = wk2[1]; ws[g] = ws2[0]; ws[g + 1] = ws2[1]; src[g] = src2[0]; src[g + 1] = src2[1];
+                }
+            } else {
+                wave_argmax2_key_x<G>(bk, bs, wk, ws, src);
+            }
             if constexpr (BH > 1 && G < BH) {
                 // never called: a split bucket occupies BH slots
             } else if constexpr (BH > 1) {
 #pragma unroll
-                for (int q = 0; q < G; q += BH) {               // the bucket's key is the largest of its parts' keys
+                for (int q = 0; q < G; q += BH) {               // the bucket's top / runner-up over its parts
                     const int j = (s_idx * 64 + ol[q]) * NW + wave;
                     int w = q;                                  // scalar
                     unsigned long long wb = wk[q];
+                    unsigned wsb = ws[q];
 #pragma unroll
-                    for (int h = 1; h < BH; ++h)
-                        if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
+                    for (int h = 1; h < BH; ++h) {
+                        if (wk[q + h] > wb) { wsb = max(wsb, max((unsigned)(wb >> 32), ws[q + h])); wb = wk[q + h]; w = q + h; }
+                        else wsb = max(wsb, (unsigned)(wk[q + h] >> 32));
+                    }
 #pragma unroll
                     for (int h = 0; h < BH; ++h)
                         if (w == q + h && lane == src[q + h]) bxyz[j] = bp[q + h];
-                    if (lane == ol[q]) key_s = wb;
-                    if (wb > cand) { cand = wb; cand_j = j; }
+                    if (lane == ol[q]) { key_s = wb; sec_s = wsb; }
+                    merge(wb, wsb, j);
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int j = (s_idx * 64 + ol[u]) * NW + wave;
                     if (lane == src[u]) bxyz[j] = bp[u];
-                    if (lane == ol[u]) key_s = wk[u];
-                    if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
+                    if (lane == ol[u]) { key_s = wk[u]; sec_s = ws[u]; }
+                    if (u == 0 || ol[u] != ol[0]) merge(wk[u], ws[u], j);      // a left-over slot repeats slot 0
                 }
             }
-#ifdef PCP_FPS_STAMPS
-            { unsigned long long tb; STAMP(tb); sRed += tb - tc0; }
-#endif
         };
         bool first = true;
+        STAMP(t1);
         __builtin_amdgcn_s_setprio(3);                          // the streaming phase is the round's critical path
 #pragma unroll
         for (int s = 0; s < CPL; ++s) {
             unsigned long long m = amask[s];
+#ifdef PCP_FPS_STAMPS
+            nAct += __popcll(m);
+#endif
             while (m) {                                         // wave-uniform
-                int ol[4], n = 0;
+#ifdef PCP_FPS_STAMPS
+                nPass += 1;
+#endif
+                int ol[4], nb = 0;
                 if constexpr (BH > 1) {                         // 4 / BH buckets per pass, BH slots each
 #pragma unroll
                     for (int u = 0; u < 4; u += BH) {
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + BH; }
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; nb = u + BH; }
                         else ol[u] = ol[0];
 #pragma unroll
                         for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
@@ -960,64 +1305,102 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {               // a fourth slot left over repeats slot 0: harmless
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; n = u + 1; }
+                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; nb = u + 1; }
                         else ol[u] = ol[0];
                     }
                 }
-#ifdef PCP_FPS_STAMPS
-                sPass += 1; sAct += n;
-#endif
                 using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
                 using I4 = std::integral_constant<int, 4>;
                 // only the cloud's last bucket can be short of rows; it belongs to lane (NB-1)/NW % 64
                 const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || (((NB - 1) / NW) >> 6) != s ||
                                   !((amask[s] >> (((NB - 1) / NW) & 63)) & 1ull);
                 if (full) {
-                    if (n == 1) run_pass(I1{}, std::true_type{}, ol, key[s], s, first);
-                    else if (n == 2) run_pass(I2{}, std::true_type{}, ol, key[s], s, first);
-                    else run_pass(I4{}, std::true_type{}, ol, key[s], s, first);
+                    if (nb == 1) run_pass(I1{}, std::true_type{}, ol, key[s], sec[s], s, first);
+                    else if (nb == 2) run_pass(I2{}, std::true_type{}, ol, key[s], sec[s], s, first);
+                    else run_pass(I4{}, std::true_type{}, ol, key[s], sec[s], s, first);
                 } else {
-                    run_pass(I4{}, std::false_type{}, ol, key[s], s, first);
+                    run_pass(I4{}, std::false_type{}, ol, key[s], sec[s], s, first);
                 }
                 first = false;
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if (first) idle_argmax();                               // nothing to stream this round
-        wmax = cand;                                            // = arg-max over all the wave's buckets again
-        wmax_j = cand_j;
+        if (first && !cached) idle_top2();                      // nothing to stream and no partial yet
+        cached = true;
         STAMP(t2);
         // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
-        if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
-        STAMP(t3);
+        if (lane == 0) {
+            const float4 bx = bxyz[cand_j];
+            pkey[wave] = cand;
+            pxyz[wave] = make_float4(bx.x, bx.y, bx.z, __uint_as_float(c2));
+        }
         // Workgroup barrier WITHOUT draining global stores: only LDS traffic (the partials) has to be
         // visible to the other waves.  The min_d stores of this round are re-read by this wave alone
         // (a bucket is streamed by its owning wave only), and same-wave accesses stay ordered, so
         // waiting for their acknowledgements — which __syncthreads() does — is wasted serial time.
+        STAMP(t3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         STAMP(t4);
-        {
-            // every low lane fetches its wave's key AND xyz in one LDS round trip; the winner's xyz is then a
-            // readlane away instead of a second, dependent LDS read
-            const unsigned long long kk = pkey[par * NW + (lane & (NW - 1))];
-            const float4 cc = pxyz[par * NW + (lane & (NW - 1))];
-            int src;
-            const unsigned long long wk = lowlanes_argmax_key<NW>(kk, &src);
-            last = wk ? (int)(~(unsigned)wk) : 0;
-            sx = rl(cc.x, src); sy = rl(cc.y, src); sz = rl(cc.z, src);
+        if (wave == 0) {                                        // the picker
+            constexpr unsigned long long LOW = (1ull << NW) - 1ull;
+            const unsigned long long kk = pkey[lane & (NW - 1)];
+            const float4 cc = pxyz[lane & (NW - 1)];
+            int src[4] = {0, 0, 0, 0};
+            (void)lowlanes_argmax_key<NW>(kk, &src[0]);
+            int np = 1;
+            const int nmax = min(4, kn - kd);
+            const unsigned rubv = __float_as_uint(cc.w);
+            unsigned v = (unsigned)(kk >> 32);
+            unsigned long long chosen = 1ull << src[0];
+            const unsigned long long selfok = __ballot(dist2<MODE>(cc.x, cc.y, cc.z, cc.x, cc.y, cc.z) == 0.f);
+#pragma unroll
+            for (int t = 1; t < 4; ++t) {
+                if (np != t || t >= nmax) break;                // all wave-uniform
+                if (!((selfok >> src[t - 1]) & 1ull)) break;    // a non-finite pick keeps its min-distance: it is next again
+                v = lane == src[t - 1] ? 0u : v;
+                unsigned m = v;
+                m = max(m, dpp_u32<0xB1>(m));
+                m = max(m, dpp_u32<0x4E>(m));
+                if (NW > 4) m = max(m, dpp_u32<0x141>(m));
+                if (NW > 8) m = max(m, dpp_u32<0x140>(m));
+                m = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
+                if (m == 0u) break;
+                const unsigned long long hit = __ballot(v == m) & LOW;
+                if (__popcll(hit) != 1) break;                  // a tie on the value: index order decides, next round
+                const int s = __ffsll((long long)hit) - 1;
+                const float d = dist2<MODE>(cc.x, cc.y, cc.z, rl(cc.x, s), rl(cc.y, s), rl(cc.z, s));
+                const unsigned long long bad = __ballot(d < __uint_as_float(m) || !(rubv < m)) & chosen;
+                if (bad) break;
+                chosen |= 1ull << s;
+                src[t] = s;
+                np = t + 1;
+            }
+            int pos = -1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < np && lane == src[t]) pos = t;
+            if (pos >= 0) {
+                const int id = kk ? (int)(~(unsigned)kk) : 0;
+                sel[pos] = make_float4(cc.x, cc.y, cc.z, __int_as_float(id));
+                irow[kd + pos] = id;
+                if (orow) { orow[3 * (kd + pos)] = cc.x; orow[3 * (kd + pos) + 1] = cc.y; orow[3 * (kd + pos) + 2] = cc.z; }
+            }
+            if (lane == 0) *nselp = np;
         }
+        STAMP(t5);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        sm = sel[lane & 3];
+        n = __builtin_amdgcn_readfirstlane(*nselp);
+        kd += n;
 #ifdef PCP_FPS_STAMPS
-        { unsigned long long t5; STAMP(t5); sA += t1 - t0; sB += t2 - t1; sR += t3 - t2; sW += t4 - t3; sC += t5 - t4;
-          if (b == 0 && lane == 0 && k >= 500 && k < 503)
-              printf("[tl] k=%d wave=%2d t0=%llu test=%llu stream=%llu part=%llu bar=%llu pick=%llu n=%d\n", k, wave,
-                     t0 % 1000000ull, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, (int)__popcll(amask[0])); }
+        { unsigned long long t6; STAMP(t6); sT += t1 - t0; sS += t2 - t1; sP += t3 - t2; sB1 += t4 - t3; sK += t5 - t4; sB2 += t6 - t5; nR += 1; }
 #endif
+        if (kd >= kn) break;
     }
 #ifdef PCP_FPS_STAMPS
-    if (b == 0 && lane == 0 && (wave == 0 || wave == NW - 1))
-        printf("[stamps] wave %d M=%d NB=%d BS=%d bits=%d rounds=%d prologue=%llu | per round: test=%llu stream=%llu reduce=%llu barrier=%llu pick=%llu cycles; passes/round=%.2f buckets/round(this wave)=%.2f | per pass: memwait=%llu compute=%llu argmax=%llu\n",
-               wave, M, NB, BS, 0, kn - 1, tp1 - tp0, sA / (kn - 1), sB / (kn - 1), sR / (kn - 1), sW / (kn - 1),
-               sC / (kn - 1), (double)sPass / (kn - 1), (double)sAct / (kn - 1), sMem / (sPass ? sPass : 1), sCmp / (sPass ? sPass : 1), sRed / (sPass ? sPass : 1));
+    if (b == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW - 1))
+        printf("[stamps] wave %d M=%d NB=%d picks=%d rounds=%llu | cycles per round: test=%llu stream=%llu publish=%llu barrier1=%llu picker=%llu barrier2+read=%llu | passes/round=%.2f buckets/round=%.2f\n",
+               wave, M, NB, kn - 1 - k0, nR, sT / nR, sS / nR, sP / nR, sB1 / nR, sK / nR, sB2 / nR, (double)nPass / nR, (double)nAct / nR);
 #endif
 }
 
@@ -1035,6 +1418,21 @@ fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ off
                                              m_cap, overflow);
 }
 
+// The wide shape with MULTI-PICK rounds, for batches of at most one workgroup per CU (<= 256 clouds): there a round is
+// bound by its dependent chain (test -> loads -> arg-max -> barrier -> pick), not by instruction issue, and certifying
+// up to four picks per round cuts the number of chains to a third.  One workgroup per CU = four waves per SIMD, so the
+// kernel may use 128 VGPRs.
+template <int T, int CPL, int MODE, int BH = 1>
+__global__ void __launch_bounds__(T)
+fps_bucket_wide_mp(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+                   long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                   float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
+                   int* __restrict__ overflow)
+{
+    fps_bucket_body<T, CPL, false, MODE, BH, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
+                                                   m_cap, overflow);
+}
+
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
 template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
@@ -1050,7 +1448,7 @@ fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ off
 // ---- host entry points -------------------------------------------------------------------------
 static int fps_pick_algo(int algo, int64_t max_pts)
 {
-    if (algo >= 2) return 2;                 // 3 / 4: bucket kernels with the deferred rounds forced on / off
+    if (algo >= 2) return 2;                 // 3 / 4: bucket kernels with the deferred rounds forced on / off; 5 / 6: multi-pick rounds on / off
     if (algo == 1) return 1;
     return max_pts >= 2048 ? 2 : 1;
 }
@@ -1080,9 +1478,13 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int m_cap;                   // largest cloud any launch of this call takes (the top shape's m_hi)
     int* overflow;
     int lazy;
+    int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, -1 = never
     hipStream_t st;
 };
 
+#ifndef PCP_FPS_MP_MAX_B
+#define PCP_FPS_MP_MAX_B 0       // multi-pick rounds for batches of at most this many clouds (0: only when asked for, algo 5)
+#endif
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
 {
@@ -1090,6 +1492,7 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
                  int, int*);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
+    else if (c.mp > 0 || (c.mp == 0 && c.B <= PCP_FPS_MP_MAX_B)) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
     else kern = fps_bucket_wide<T, CPL, MODE, BH>;
     // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
     // (lazy: 0 = by batch size, 1 = always, -1 = never)
@@ -1146,7 +1549,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
                             void* ws, size_t ws_bytes, hipStream_t st)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
-        algo < 0 || algo > 4)
+        algo < 0 || algo > 6)
         return PCP_ERR_INVALID_ARG;
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
@@ -1160,6 +1563,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
     c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
     c.lazy = algo == 3 ? 1 : (algo == 4 ? -1 : 0);
+    c.mp = algo == 5 ? 1 : (algo == 6 ? -1 : 0);
     c.st = st;
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);

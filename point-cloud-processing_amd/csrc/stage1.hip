@@ -477,6 +477,43 @@ k1_gather_pixels(const float* __restrict__ depth, const uint8_t* __restrict__ rg
     o[0] = col[0]; o[1] = col[1]; o[2] = col[2];
 }
 
+// The same walk, but the result is WHERE the colour sits, not the colour: the colour-image pixel v_idx * Wc + u_idx of
+// XPC:73-77 for every sampled point, -1 where align_colors masks the point (its colour stays zero, XPC:76) or the
+// row does not exist.  A caller that keeps the rgb images in host memory then needs no rgb upload at all: the
+// projection mask depends on rgb.shape only (XPC:72-75) and colours are wanted for the K sampled points.
+__global__ void __launch_bounds__(256)
+k1_sampled_color_pixels(const float* __restrict__ depth, int HW, int W, int Hc, int Wc, DevParams P,
+                        const int32_t* __restrict__ pix, const long long* __restrict__ offsets, long long total_pts,
+                        const long long* __restrict__ idx, int K, int compat_neg, int32_t* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long base = offsets[b], M = offsets[b + 1] - base;
+    long long i = idx[(size_t)b * K + k];
+    int32_t* o = out + (size_t)b * K + k;
+    if (i < 0) {
+        if (compat_neg && M > 0 && i + M >= 0) i += M;        // numpy negative indexing, DP3:48
+        else { *o = -1; return; }
+    }
+    if (i >= M || base < 0 || base + i >= total_pts) { *o = -1; return; }
+    const int p = pix[base + i];
+    if (p < 0 || p >= HW) { *o = -1; return; }
+    int pv, pu;
+    pcp_divmod(p, W, 1.0f / (float)W, &pv, &pu);
+    const double z = (double)depth[(size_t)b * HW + p];
+    const double cam[3] = {(((double)pu - P.dcx) * z) / P.dfx, (((double)pv - P.dcy) * z) / P.dfy, z};
+    double cf[3];
+    rigid3(P.T, 1, cam[0], cam[1], cam[2], cf);                   // XPC:67-68, as align_math
+    double zdiv = cf[2] > P.zc_clamp ? cf[2] : P.zc_clamp;
+    if (cf[2] != cf[2]) zdiv = cf[2];
+    const double uc = ((cf[0] * P.cfx) / zdiv) + P.ccx;
+    const double vc = ((cf[1] * P.cfy) / zdiv) + P.ccy;
+    const double ur = rint(uc), vr = rint(vc);
+    const bool inside = (ur >= 0.0) && (ur < (double)Wc) && (vr >= 0.0) && (vr < (double)Hc);
+    *o = (inside && (cf[2] > P.zc_min)) ? (int32_t)((long long)vr * Wc + (long long)ur) : -1;
+}
+
 // fused (all cameras of a frame) CSR offsets: every C-th entry of the per-image offsets
 __global__ void k1_fused_offsets(const long long* __restrict__ offsets, int F, int C, long long* __restrict__ fused)
 {
@@ -592,6 +629,21 @@ extern "C" int pcp_gather_rgb_pixels(const float* depth, const uint8_t* rgb, int
     hipLaunchKernelGGL(k1_gather_pixels, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, depth, rgb,
                        H * W, W, Hc, Wc, pcp_to_dev(p), pix, (const long long*)offsets, (long long)total_pts,
                        (const long long*)idx, K, compat_neg_index, out);
+    return pcp_launch_status();
+}
+
+extern "C" int pcp_sampled_color_pixels(const float* depth, int B, int H, int W, int Hc, int Wc, const pcp_params* p,
+                                        const int32_t* pix, const int64_t* offsets, int64_t total_pts,
+                                        const int64_t* idx, int K, int compat_neg_index, int32_t* cpix, void* stream)
+{
+    if (B < 0 || K < 0 || total_pts < 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || !params_ok(p))
+        return PCP_ERR_INVALID_ARG;
+    if ((long long)H * W > 0x7fffffffLL / 4 || H >= (1 << 20) || (long long)Hc * Wc > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
+    if (B == 0 || K == 0) return PCP_OK;
+    if (!depth || !offsets || !idx || !cpix || (total_pts > 0 && !pix)) return PCP_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(k1_sampled_color_pixels, dim3((K + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, depth,
+                       H * W, W, Hc, Wc, pcp_to_dev(p), pix, (const long long*)offsets, (long long)total_pts,
+                       (const long long*)idx, K, compat_neg_index, cpix);
     return pcp_launch_status();
 }
 

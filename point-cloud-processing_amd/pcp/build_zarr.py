@@ -82,17 +82,73 @@ def _process_traj(data_root, traj, source, K, frame_skip, intr, ext, runner_box)
     return rows, action, state
 
 
+def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=None):
+    """The dataset-level loop of BASELINE configs[3] (S2:34-45 + CHK:47-200) for any episode source.
+      lengths[i]  expected frame count of episode i (only used to balance the ranks)
+      produce(i)  → None (episode skipped, CHK:67-70 / 127-132) or (rows (n,K,6), action (n,7), state (n,7))
+    Under torch.distributed (one process per GPU) the episodes are dealt to the ranks in contiguous, frame-balanced
+    blocks; every rank runs `produce` for its own, then compresses and writes the point-cloud chunks its rows fill
+    (shard.write_rows_sharded) — no rank ever holds another rank's rows, nothing is stacked on rank 0, and the only
+    data that travels is the rows of the few chunks straddling two ranks plus the (n,7) state / action arrays.
+    Rank 0 writes .zarray / action / state / episode_ends.  The store equals a single-process run's byte for byte.
+    Returns (total frames, episodes kept)."""
+    import time
+    from pcp import shard
+    dist, rank, world = shard._dist()
+    t0 = time.perf_counter()
+    mine = shard.assign_contiguous(lengths, world)[rank]
+    local_rows, local_meta = {}, {}
+    for i in mine:
+        res = produce(i)
+        if res is None:
+            local_meta[i] = None
+            continue
+        rows, action, state = res
+        rows = np.ascontiguousarray(np.asarray(rows, dtype=np.float32))      # CHK:195 stores float32
+        local_rows[i] = rows
+        local_meta[i] = (rows.shape, np.asarray(action), np.asarray(state))
+    t1 = time.perf_counter()
+    shapes = {}
+    for part in shard.all_gather_small({i: (None if m is None else m[0]) for i, m in local_meta.items()}):
+        shapes.update(part)
+    missing = [i for i in range(len(lengths)) if i not in shapes]
+    if missing:
+        raise RuntimeError(f"episodes {missing} were processed by no rank")
+    kept = [i for i in range(len(lengths)) if shapes[i] is not None]
+    if not kept:
+        raise RuntimeError("no complete trajectory found")
+    tails = {tuple(shapes[i][1:]) for i in kept if shapes[i][0] > 0} or {tuple(shapes[kept[0]][1:])}
+    if len(tails) != 1:
+        raise ValueError(f"episodes disagree on the cloud shape: {sorted(tails)}")     # np.stack would fail, CHK:158
+    counts = [0 if shapes[i] is None else int(shapes[i][0]) for i in range(len(lengths))]
+    if rank == 0:
+        zarr_store.create_dp3_layout(out_zarr)
+    shard.barrier()
+    wrote = shard.write_rows_sharded(os.path.join(out_zarr, "data", "point_cloud"), local_rows, counts, tails.pop(),
+                                     CHUNK_SIZE, "<f4", compressor, threads)
+    metas = shard.gather_to_root({i: (m[1], m[2]) for i, m in local_meta.items() if m is not None})
+    if metas is not None:
+        merged = {}
+        for part in metas:
+            merged.update(part)
+        ends = np.cumsum([counts[i] for i in kept]).astype(np.int64)                    # CHK:151-152
+        zarr_store.write_dp3_small_arrays(out_zarr, np.vstack([merged[i][0] for i in kept]),
+                                          np.vstack([merged[i][1] for i in kept]), ends, CHUNK_SIZE, compressor)
+    shard.barrier()
+    if timing is not None:
+        timing.update(produce_s=t1 - t0, write_s=time.perf_counter() - t1, chunks_written_here=wrote[0],
+                      boundary_pieces_sent=wrote[1], episodes_here=len(mine))
+    return int(sum(counts)), len(kept)
+
+
 def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, compressor="zlib", intr=None,
           ext=None):
     """source='ply': read <traj>/filtered_point_clouds (the reference's route).
     source='gpu': run depth+rgb of <traj>/extracted_data/<traj> through the GPU path directly.
-    Under torch.distributed (one process per GPU, BASELINE configs[3]) whole trajectories are dealt to the
-    ranks longest-first, every rank processes its own on its own GPU, the blocks are gathered host-side in
-    sorted-trajectory order and rank 0 writes the store — `episode_ends` equals the single-process run's."""
+    Under torch.distributed (one process per GPU, BASELINE configs[3]) see assemble()."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     rank = dist.get_rank() if distributed else 0
-    world = dist.get_world_size() if distributed else 1
     trajs = []
     for traj in sorted(d for d in os.listdir(data_root) if os.path.isdir(os.path.join(data_root, d))):
         extracted = os.path.join(data_root, traj, "extracted_data", traj)
@@ -105,8 +161,7 @@ def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, comp
                 print(f"Skipping {traj}: Missing one or more data components.")        # CHK:67-70
             continue
         trajs.append(traj)
-    from pcp import shard
-    mine = shard.assign_episodes([_count_states(os.path.join(data_root, t, "extracted_data", t)) for t in trajs], world)[rank]
+    lengths = [_count_states(os.path.join(data_root, t, "extracted_data", t)) for t in trajs]
     runner_box = {}
     if source == "gpu":
         import torch
@@ -116,24 +171,16 @@ def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, comp
         local_dev = int(os.environ.get("LOCAL_RANK", "0")) % ndev       # rehearsals with more ranks than GPUs share devices
         torch.cuda.set_device(local_dev)                                # libpcp launches on the current device
         runner_box["device"] = f"cuda:{local_dev}"
-    local = {i: _process_traj(data_root, trajs[i], source, K, frame_skip, intr, ext, runner_box) for i in mine}
-    results = shard.gather_episodes(local, len(trajs))
-    pcs, actions, states, ends, total = [], [], [], [], 0
-    for res in results:
+
+    def produce(i):
+        res = _process_traj(data_root, trajs[i], source, K, frame_skip, intr, ext, runner_box)
         if res is None:
-            continue
+            return None
         rows, action, state = res
-        pcs.extend(rows); actions.append(action); states.append(state)
-        total += state.shape[0]
-        ends.append(total)                                                           # CHK:151-152
-    if not pcs:
-        raise RuntimeError("no complete trajectory found")
-    if rank == 0:
-        zarr_store.write_dp3_dataset(out_zarr, np.stack(pcs, axis=0), np.vstack(actions), np.vstack(states),
-                                     np.array(ends, dtype=np.int64), CHUNK_SIZE, compressor)
-    if distributed:
-        dist.barrier()
-    return total, len(ends)
+        rows = np.asarray(rows, dtype=np.float32) if len(rows) else np.zeros((0, K, 6), np.float32)
+        return rows, action, state
+
+    return assemble(lengths, produce, out_zarr, compressor)
 
 
 def main():

@@ -13,7 +13,13 @@ from . import _ffi, ops
 
 class EpisodeRunner:
     def __init__(self, H, W, K, params, device="cuda", chunk=64, dist_mode=None, Hc=None, Wc=None, depth_mm=False,
-                 stage_threads=8, upload_piece=25):
+                 stage_threads=8, upload_piece=25, rgb_on_host=True, profile=False):
+        """rgb_on_host (default): the rgb images never leave host memory.  align_colors' mask needs rgb.shape only
+        (XPC:72-75) and colours are wanted for the K sampled points (DP3:48), so the device returns each sampled
+        point's colour-image pixel (pcp_sampled_color_pixels) and the rows' colour half is gathered from the host
+        images: per 640x480 frame 0.6 MB (u16 depth) or 1.2 MB (f32) cross PCIe instead of 1.5 / 2.2 MB.  False: rgb
+        is uploaded and gathered on the device (pcp_gather_rgb_pixels) — same rows, bit for bit.
+        profile: accumulate a host / PCIe / kernel time breakdown in self.stats (adds timing events)."""
         if not torch.cuda.is_available():
             raise RuntimeError("pcp needs a ROCm device (MI355X); there is no CPU fallback")
         self.H, self.W, self.K, self.params, self.chunk = H, W, K, params, int(chunk)
@@ -30,10 +36,19 @@ class EpisodeRunner:
         mk = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
         ddt = torch.uint16 if self.depth_mm else torch.float32
         self.h_depth = [mk((self.chunk, H, W), ddt) for _ in range(2)]
-        self.h_rgb = [mk((self.chunk, self.Hc, self.Wc, 3), torch.uint8) for _ in range(2)]
+        self.rgb_on_host = bool(rgb_on_host)
         self.d_depth = [torch.empty((self.chunk, H, W), dtype=ddt, device=self.dev) for _ in range(2)]
         self.d_depth_m = torch.empty((self.chunk, H, W), dtype=torch.float32, device=self.dev) if self.depth_mm else None
-        self.d_rgb = [torch.empty((self.chunk, self.Hc, self.Wc, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        if self.rgb_on_host:
+            self.h_rgb = self.d_rgb = None
+            self.h_xyz = mk((self.chunk, K, 3), torch.float32)
+            self.h_cpix = mk((self.chunk, K), torch.int32)
+        else:
+            self.h_rgb = [mk((self.chunk, self.Hc, self.Wc, 3), torch.uint8) for _ in range(2)]
+            self.d_rgb = [torch.empty((self.chunk, self.Hc, self.Wc, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.profile = bool(profile)
+        self.stats = dict(frames=0, chunks=0, stage_s=0.0, wait_s=0.0, host_rows_s=0.0, h2d_ms=0.0, kernels_ms=0.0, d2h_ms=0.0)
+        self._ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(2)] if self.profile else None
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         self.h_rows = mk((self.chunk, K, 6), torch.float32)
@@ -77,17 +92,26 @@ class EpisodeRunner:
         piece = max(1, self.upload_piece)
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.consumed[slot])
+            if self.profile:
+                self._ev[slot][0].record(self.copy_stream)
+        import time
         for a in range(0, max(n, 1), piece):
             b = min(a + piece, n)
             if b > a:
+                t0 = time.perf_counter()
                 self._stage(self.h_depth[slot][a:b], depth[a:b])
-                self._stage(self.h_rgb[slot][a:b], rgb[a:b])
+                if not self.rgb_on_host:
+                    self._stage(self.h_rgb[slot][a:b], rgb[a:b])
+                self.stats["stage_s"] += time.perf_counter() - t0
             last = b >= n
             hi = self.chunk if last else b                   # the last piece carries the zeroed tail too
             with torch.cuda.stream(self.copy_stream):
                 self.d_depth[slot][a:hi].copy_(self.h_depth[slot][a:hi], non_blocking=True)
-                self.d_rgb[slot][a:hi].copy_(self.h_rgb[slot][a:hi], non_blocking=True)
+                if not self.rgb_on_host:
+                    self.d_rgb[slot][a:hi].copy_(self.h_rgb[slot][a:hi], non_blocking=True)
                 if last:
+                    if self.profile:
+                        self._ev[slot][1].record(self.copy_stream)
                     self.uploaded[slot].record(self.copy_stream)
             if last:
                 break
@@ -100,7 +124,20 @@ class EpisodeRunner:
         with torch.cuda.device(self.dev):                    # events, streams and kernels all belong to self.dev
             return self._run_chunks(chunks)
 
+    def _host_rows(self, n, rgb):
+        """(n,K,6) DP3 rows from the chunk's xyz + colour pixels and the HOST rgb images: colours[mask] = rgb[v_idx,
+        u_idx] / 255 (XPC:77), zero where masked (XPC:76), times 255 again in the row (CHK:141) = the u8 value."""
+        out = np.empty((n, self.K, 6), np.float32)
+        out[:, :, :3] = self.h_xyz[:n].numpy()
+        cp = self.h_cpix[:n].numpy()
+        flat = np.ascontiguousarray(rgb[:n]).reshape(n, self.Hc * self.Wc, 3)
+        got = np.take_along_axis(flat, np.maximum(cp, 0)[:, :, None].astype(np.int64), axis=1)
+        out[:, :, 3:] = got
+        out[:, :, 3:][cp < 0] = 0.0
+        return out
+
     def _run_chunks(self, chunks):
+        import time
         rows, counts = [], []
         main = torch.cuda.current_stream(self.dev)
         for s in range(2):
@@ -113,25 +150,52 @@ class EpisodeRunner:
         while nxt is not None:
             cur_n, cur_slot = nxt[0].shape[0], slot
             main.wait_event(self.uploaded[cur_slot])
+            ev = self._ev[cur_slot] if self.profile else None
+            if ev:
+                ev[2].record(main)
             dsrc = ops.depth_mm_to_m(self.d_depth[cur_slot], self.d_depth_m) if self.depth_mm else self.d_depth[cur_slot]
-            xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[cur_slot])
-            packed = ops.pack_dp3(xyz, col)
-            self.consumed[cur_slot].record(main)
-            self.h_rows.copy_(packed, non_blocking=True)
+            if self.rgb_on_host:
+                cur_rgb = nxt[1]                                 # stays on the host; read again when the pixels are known
+                xyz, cpix, idx, off = self.pipe.run_host_rgb(dsrc, self.Hc, self.Wc)
+                self.consumed[cur_slot].record(main)
+                if ev:
+                    ev[3].record(main)
+                self.h_xyz.copy_(xyz, non_blocking=True)
+                self.h_cpix.copy_(cpix, non_blocking=True)
+            else:
+                xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[cur_slot])
+                packed = ops.pack_dp3(xyz, col)
+                self.consumed[cur_slot].record(main)
+                if ev:
+                    ev[3].record(main)
+                self.h_rows.copy_(packed, non_blocking=True)
             self.h_off.copy_(off, non_blocking=True)
             self.h_flags[0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
             self.h_flags[1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
+            if ev:
+                ev[4].record(main)
             self.done.record(main)
             nxt = next(it, None)
             if nxt is not None:
                 slot ^= 1
                 self._upload(slot, *nxt)
+            t0 = time.perf_counter()
             self.done.synchronize()
+            t1 = time.perf_counter()
             if int(self.h_flags[0]) or int(self.h_flags[1]):
                 raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if int(self.h_flags[0]) else
                                     "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
-            rows.append(self.h_rows[:cur_n].numpy().copy())
+            if self.rgb_on_host:
+                rows.append(self._host_rows(cur_n, cur_rgb))
+            else:
+                rows.append(self.h_rows[:cur_n].numpy().copy())
             counts.append(np.diff(self.h_off.numpy())[:cur_n])
+            st = self.stats
+            st["wait_s"] += t1 - t0; st["host_rows_s"] += time.perf_counter() - t1
+            st["frames"] += cur_n; st["chunks"] += 1
+            if ev:                                              # the chunk's events have all completed by now
+                st["h2d_ms"] += ev[0].elapsed_time(ev[1]); st["kernels_ms"] += ev[2].elapsed_time(ev[3])
+                st["d2h_ms"] += ev[3].elapsed_time(ev[4])
         if not rows:
             return np.zeros((0, self.K, 6), np.float32), np.zeros((0,), np.int64)
         return np.concatenate(rows), np.concatenate(counts)

@@ -124,13 +124,20 @@ class Stage1:
         self.offsets = torch.zeros(B + 1, dtype=torch.int64, device=device)
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)
 
-    def run(self, depth, rgb, params):
+    def run(self, depth, rgb, params, Hc=None, Wc=None):
+        """rgb may be None (pass the colour image size as Hc, Wc) when no colour output was asked for: the projection
+        mask needs rgb.shape only (XPC:72-75)."""
         _require_cuda(depth, rgb)
-        _chk(depth, torch.float32, "depth"); _chk(rgb, torch.uint8, "rgb")
+        _chk(depth, torch.float32, "depth")
         B, H, W = depth.shape
         if (B, H, W) != (self.B, self.H, self.W):
             raise ValueError("depth shape does not match the Stage1 plan")
-        Hc, Wc = rgb.shape[1], rgb.shape[2]
+        if rgb is None:
+            if "rgb32" in self.out or Hc is None or Wc is None:
+                raise ValueError("rgb = None needs Hc, Wc and a plan without the rgb32 output")
+        else:
+            _chk(rgb, torch.uint8, "rgb")
+            Hc, Wc = rgb.shape[1], rgb.shape[2]
         g = lambda k: _ptr(self.out.get(k))
         _call(self.device, load_library().pcp_backproject_align_crop,
               _ptr(depth), _ptr(rgb), B, H, W, Hc, Wc, C.byref(params), g("xyz_cam64"), g("xyz64"),
@@ -249,11 +256,16 @@ class Fps:
 
 
 def fps_batched(xyz, offsets, K, dist_mode=0, algo=0, max_pts=None):
+    """One-shot pcp_fps_batched (allocates its plan, synchronises once to read the overflow flag): raises PcpError
+    when a cloud could not be sampled — more points than `max_pts` promised, or offsets reaching past `xyz`."""
     B = offsets.numel() - 1
     if max_pts is None:
         max_pts = xyz.shape[0]
     plan = Fps(B, xyz.shape[0], max_pts, K, xyz.device, dist_mode, algo)
-    return plan.run(xyz, offsets)
+    out = plan.run(xyz, offsets)
+    if int(plan.overflow.item()):
+        raise _ffi.PcpError(-3, "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
+    return out
 
 
 def gather_rgb(rgb, offsets, idx, compat_neg_index=True):
@@ -280,6 +292,23 @@ def gather_rgb_pixels(depth, rgb, params, pix, offsets, idx, compat_neg_index=Tr
         out = torch.empty((B, K, 3), dtype=torch.float32, device=depth.device)
     _call(depth.device, load_library().pcp_gather_rgb_pixels, _ptr(depth), _ptr(rgb), B, H, W, rgb.shape[1], rgb.shape[2],
           C.byref(params), _ptr(pix), _ptr(offsets), pix.shape[0], _ptr(idx), K, 1 if compat_neg_index else 0, _ptr(out))
+    return out
+
+
+def sampled_color_pixels(depth, Hc, Wc, params, pix, offsets, idx, compat_neg_index=True, out=None):
+    """Colour-image pixel (v_idx*Wc + u_idx, -1 = masked) of every sampled point (pcp_sampled_color_pixels): what a
+    caller with the rgb images in HOST memory needs to finish pc_rgb[idx] (DP3:48) without ever uploading rgb."""
+    _require_cuda(depth, pix, offsets, idx)
+    _chk(depth, torch.float32, "depth"); _chk(pix, torch.int32, "pix")
+    _chk(offsets, torch.int64, "offsets"); _chk(idx, torch.int64, "idx")
+    B, H, W = depth.shape
+    K = idx.shape[1]
+    if idx.shape[0] != B or offsets.numel() != B + 1:
+        raise ValueError("idx / offsets do not match the batch")
+    if out is None:
+        out = torch.empty((B, K), dtype=torch.int32, device=depth.device)
+    _call(depth.device, load_library().pcp_sampled_color_pixels, _ptr(depth), B, H, W, int(Hc), int(Wc), C.byref(params),
+          _ptr(pix), _ptr(offsets), pix.shape[0], _ptr(idx), K, 1 if compat_neg_index else 0, _ptr(out))
     return out
 
 
@@ -383,7 +412,9 @@ class FramePipeline:
     """The whole hot path for batches of B frames: depth+rgb → (B,K,3) xyz, (B,K,3) rgb,
     (B,K) idx.  All buffers are allocated once; run() only enqueues kernels."""
 
-    def __init__(self, B, H, W, K, params, device="cuda", dist_mode=0, algo=0, cap_per_frame=None):
+    def __init__(self, B, H, W, K, params, device="cuda", dist_mode=None, algo=0, cap_per_frame=None):
+        if dist_mode is None:                   # the loop this replaces samples with use_cuda=True (DP3:47)
+            dist_mode = dist_mode_for(True)
         self.B, self.H, self.W, self.K, self.params = B, H, W, K, params
         cap = B * (cap_per_frame if cap_per_frame is not None else H * W)
         # colours are fetched for the K sampled points only (gather_rgb_pixels): stage 1 writes xyz32 + the source pixel
@@ -399,6 +430,19 @@ class FramePipeline:
         f.enqueue(out["xyz32"], offsets, self.stage1.cap)
         self.gather(depth, rgb)
         return f.xyz, self.rgb_out, f.idx, offsets
+
+    def run_host_rgb(self, depth, Hc, Wc):
+        """The same path for a caller whose rgb images stay in HOST memory: nothing but depth is read on the device.
+        Returns (xyz (B,K,3), cpix (B,K) i32, idx, offsets); colour = rgb_b.reshape(-1,3)[cpix] / 255, zero where
+        cpix < 0 (ops.sampled_color_pixels)."""
+        out, offsets = self.stage1.run(depth, None, self.params, Hc=Hc, Wc=Wc)
+        f, s1 = self.fps, self.stage1
+        f.enqueue(out["xyz32"], offsets, s1.cap)
+        if getattr(self, "cpix_out", None) is None:
+            self.cpix_out = torch.empty((self.B, self.K), dtype=torch.int32, device=f.device)
+        _call(f.device, load_library().pcp_sampled_color_pixels, _ptr(depth), f.B, self.H, self.W, int(Hc), int(Wc),
+              C.byref(self.params), _ptr(s1.out["pix"]), _ptr(s1.offsets), s1.cap, _ptr(f.idx), f.K, 1, _ptr(self.cpix_out))
+        return f.xyz, self.cpix_out, f.idx, offsets
 
     def gather(self, depth, rgb):
         """pc_rgb[idx] (DP3:48) for the last run's picks → self.rgb_out."""

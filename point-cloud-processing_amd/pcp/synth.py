@@ -12,11 +12,25 @@ S1_EXTRINSICS = np.array([[-0.5777, 0.4385, -0.6884, 0.7814],
                           [0.0, 0.0, 0.0, 1.0]])
 
 
-def frame(seed, H=480, W=640, Hc=None, Wc=None):
+def frame_mm(seed, H=480, W=640, Hc=None, Wc=None):
+    """The raw form of frame(): depth as the u16 millimetres a depth topic carries (XTP:68-72 divides by 1000)."""
     rng = np.random.default_rng(seed)
     depth_mm = rng.integers(300, 1500, (H, W)).astype(np.uint16)
-    depth = (depth_mm.astype(np.float32) / 1000.0).astype(np.float32)
     rgb = rng.integers(0, 256, (Hc or H, Wc or W, 3), dtype=np.uint8)
+    return depth_mm, rgb
+
+
+def frame(seed, H=480, W=640, Hc=None, Wc=None):
+    depth_mm, rgb = frame_mm(seed, H, W, Hc, Wc)
+    depth = (depth_mm.astype(np.float32) / 1000.0).astype(np.float32)
+    return depth, rgb
+
+
+def episode_mm(n_frames, seed0=0, H=480, W=640):
+    depth = np.empty((n_frames, H, W), np.uint16)
+    rgb = np.empty((n_frames, H, W, 3), np.uint8)
+    for i in range(n_frames):
+        depth[i], rgb[i] = frame_mm(seed0 + i, H, W)
     return depth, rgb
 
 

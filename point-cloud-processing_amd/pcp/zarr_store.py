@@ -36,28 +36,63 @@ def create_group(path):
     _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
 
 
-def write_array(path, data, chunks, dtype, compressor="zlib"):
-    """One zarr-v2 array: .zarray + one file per chunk ("i.j.k"), edge chunks zero-padded."""
-    data = np.ascontiguousarray(np.asarray(data).astype(dtype))
-    chunks = tuple(int(min(c, s)) if s > 0 else int(max(c, 1)) for c, s in zip(chunks, data.shape))
+def chunk_grid(shape, chunks):
+    """Effective chunk shape (zarr clamps a chunk edge to the array edge, never below 1) and chunks per axis."""
+    chunks = tuple(int(min(c, s)) if s > 0 else int(max(c, 1)) for c, s in zip(chunks, shape))
     chunks = tuple(max(c, 1) for c in chunks)
+    return chunks, [-(-s // c) for s, c in zip(shape, chunks)]
+
+
+def write_zarray(path, shape, chunks, dtype, compressor="zlib"):
+    """Create the array directory and its .zarray; returns (meta, effective chunk shape)."""
+    chunks, _ = chunk_grid(shape, chunks)
     os.makedirs(path, exist_ok=True)
     dt = np.dtype(dtype)
     meta = {"chunks": list(chunks), "compressor": _compressor_meta(compressor), "dtype": dt.str,
             "fill_value": 0 if dt.kind in "iu" else 0.0, "filters": None, "order": "C",
-            "shape": list(data.shape), "zarr_format": 2}
+            "shape": [int(n) for n in shape], "zarr_format": 2}
     _write_json(os.path.join(path, ".zarray"), meta)
-    grid = [-(-s // c) for s, c in zip(data.shape, chunks)]
-    for cidx in np.ndindex(*grid):
+    return meta, chunks
+
+
+def write_chunk(path, cidx, block, compressor="zlib"):
+    """One chunk file "i.j.k" from a FULL-chunk-shaped C-contiguous block (edge chunks zero-padded by the caller)."""
+    raw = np.ascontiguousarray(block).tobytes()
+    comp = _compressor_meta(compressor)
+    if comp:
+        raw = zlib.compress(raw, comp["level"])                 # releases the GIL: chunks compress in parallel threads
+    with open(os.path.join(path, ".".join(str(int(i)) for i in cidx)), "wb") as fh:
+        fh.write(raw)
+
+
+def write_array(path, data, chunks, dtype, compressor="zlib", threads=1):
+    """One zarr-v2 array: .zarray + one file per chunk ("i.j.k"), edge chunks zero-padded.  threads > 1 compresses and
+    writes the chunks on a thread pool."""
+    data = np.asarray(data)
+    if data.dtype != np.dtype(dtype) or not data.flags.c_contiguous:
+        data = np.ascontiguousarray(data.astype(dtype))
+    meta, chunks = write_zarray(path, data.shape, chunks, dtype, compressor)
+    dt = np.dtype(dtype)
+    _, grid = chunk_grid(data.shape, chunks)
+
+    def one(cidx):
         sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(cidx, chunks, data.shape))
-        block = np.zeros(chunks, dtype=dt)
         part = data[sl]
-        block[tuple(slice(0, n) for n in part.shape)] = part
-        raw = block.tobytes()
-        if meta["compressor"]:
-            raw = zlib.compress(raw, meta["compressor"]["level"])
-        with open(os.path.join(path, ".".join(str(i) for i in cidx)), "wb") as fh:
-            fh.write(raw)
+        if part.shape == chunks:
+            block = part
+        else:
+            block = np.zeros(chunks, dtype=dt)
+            block[tuple(slice(0, n) for n in part.shape)] = part
+        write_chunk(path, cidx, block, compressor)
+
+    cells = list(np.ndindex(*grid))
+    if threads > 1 and len(cells) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(one, cells))
+    else:
+        for c in cells:
+            one(c)
     return meta
 
 
@@ -83,22 +118,33 @@ def read_array(path):
     return out, meta
 
 
-def write_dp3_dataset(out_zarr, point_cloud, action, state, episode_ends, chunk_size=100, compressor="zlib"):
-    """CHK:175-200: overwrite <out_zarr> with the DP3 layout."""
+def create_dp3_layout(out_zarr):
+    """CHK:175-187: wipe an existing store, create the root, `data` and `meta` groups."""
     if os.path.exists(out_zarr):
         print(f"Overwriting existing Zarr file: {out_zarr}")           # CHK:175-177
         shutil.rmtree(out_zarr)
-    point_cloud, action, state = np.asarray(point_cloud), np.asarray(action), np.asarray(state)
-    episode_ends = np.asarray(episode_ends, dtype=np.int64)
     create_group(out_zarr)
     create_group(os.path.join(out_zarr, "data"))
     create_group(os.path.join(out_zarr, "meta"))
-    write_array(os.path.join(out_zarr, "data", "point_cloud"), point_cloud,
-                (chunk_size,) + tuple(point_cloud.shape[1:]), "<f4", compressor)       # CHK:188,195
+
+
+def write_dp3_small_arrays(out_zarr, action, state, episode_ends, chunk_size=100, compressor="zlib"):
+    """data/action, data/state, meta/episode_ends (CHK:196-200)."""
+    action, state = np.asarray(action), np.asarray(state)
+    episode_ends = np.asarray(episode_ends, dtype=np.int64)
     write_array(os.path.join(out_zarr, "data", "action"), action, (chunk_size, action.shape[1]), "<f4", compressor)
     write_array(os.path.join(out_zarr, "data", "state"), state, (chunk_size, state.shape[1]), "<f4", compressor)
     write_array(os.path.join(out_zarr, "meta", "episode_ends"), episode_ends, (max(len(episode_ends), 1),),
                 "<i8", compressor)                                                     # CHK:200
+
+
+def write_dp3_dataset(out_zarr, point_cloud, action, state, episode_ends, chunk_size=100, compressor="zlib", threads=1):
+    """CHK:175-200: overwrite <out_zarr> with the DP3 layout."""
+    create_dp3_layout(out_zarr)
+    point_cloud = np.asarray(point_cloud)
+    write_array(os.path.join(out_zarr, "data", "point_cloud"), point_cloud,
+                (chunk_size,) + tuple(point_cloud.shape[1:]), "<f4", compressor, threads)   # CHK:188,195
+    write_dp3_small_arrays(out_zarr, action, state, episode_ends, chunk_size, compressor)
 
 
 def read_dp3_dataset(out_zarr):

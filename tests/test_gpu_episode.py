@@ -92,3 +92,47 @@ def test_depth_mm_upload_path_equals_float_path_and_numpy_division():
     a, ca = EpisodeRunner(H, W, K, p, chunk=4, depth_mm=True).run_arrays(mm, rgb)
     b, cb = EpisodeRunner(H, W, K, p, chunk=4).run_arrays(mm.astype(np.float32) / 1000.0, rgb)
     np.testing.assert_array_equal(a, b); np.testing.assert_array_equal(ca, cb)
+
+
+def test_rgb_stays_on_the_host_and_the_rows_are_the_same():
+    """XPC:72-77: the projection mask needs rgb.shape only and colours are wanted for K points, so the runner's
+    default keeps rgb in host memory (pcp_sampled_color_pixels + a host gather).  Rows must equal the device-side
+    colour route bit for bit and the oracle's — also with a colour image of another size than the depth image, with
+    raw u16 depth, and for clouds with fewer than K points (-1 padding → the LAST cropped row's colour, DP3:48)."""
+    import torch
+    from pcp import _ffi, ops
+    from pcp.episode import EpisodeRunner
+    H, W, Hc, Wc, K, T = 60, 80, 45, 70, 160, 13
+    di = dict(fx=75.6, fy=75.6, cx=W / 2, cy=H / 2)
+    ci = dict(fx=66.0, fy=56.0, cx=Wc / 2 - 1.5, cy=Hc / 2 + 0.75)
+    rng = np.random.default_rng(21)
+    mm = rng.integers(300, 1500, (T, H, W)).astype(np.uint16)
+    mm[3, 10:, :] = 0                                                  # a sparse frame: fewer than K survivors
+    mm[7] = 0                                                          # an empty one
+    rgb = rng.integers(0, 256, (T, Hc, Wc, 3), dtype=np.uint8)
+    depth = mm.astype(np.float32) / 1000.0
+    p = _ffi.make_params(di, ci, apply_crop=True)
+    host = EpisodeRunner(H, W, K, p, chunk=5, Hc=Hc, Wc=Wc, rgb_on_host=True, profile=True)
+    devc = EpisodeRunner(H, W, K, p, chunk=5, Hc=Hc, Wc=Wc, rgb_on_host=False)
+    a, ca = host.run_arrays(depth, rgb)
+    b, cb = devc.run_arrays(depth, rgb)
+    np.testing.assert_array_equal(a, b); np.testing.assert_array_equal(ca, cb)
+    assert host.d_rgb is None and host.stats["frames"] == T and host.stats["kernels_ms"] > 0
+    assert 0 < ca[3] < K and ca[7] == 0 and (a[7] == 0).all()
+    po = cbind.make_params(di, ci, apply_crop=1)
+    for t in range(T):
+        r = cbind.frame_pipeline(depth[t], rgb[t], po, K, 1)
+        np.testing.assert_array_equal(a[t], cbind.pack_dp3(r["xyz"], r["rgb"]))
+    c, cc = EpisodeRunner(H, W, K, p, chunk=4, Hc=Hc, Wc=Wc, depth_mm=True).run_arrays(mm, rgb)
+    np.testing.assert_array_equal(c, a); np.testing.assert_array_equal(cc, ca)
+    # the operator itself: pixel indices reproduce the device gather
+    pipe = ops.FramePipeline(T, H, W, K, p)
+    d_dev, c_dev = torch.from_numpy(depth).cuda(), torch.from_numpy(rgb).cuda()
+    xyz, col, idx, off = pipe.run(d_dev, c_dev)
+    cpix = ops.sampled_color_pixels(d_dev, Hc, Wc, p, pipe.stage1.out["pix"], off, idx).cpu().numpy()
+    col = col.cpu().numpy()
+    flat = rgb.reshape(T, Hc * Wc, 3)
+    want = np.take_along_axis(flat, np.maximum(cpix, 0)[:, :, None].astype(np.int64), axis=1).astype(np.float64) / 255.0
+    want[cpix < 0] = 0.0
+    np.testing.assert_array_equal(col, want.astype(np.float32))        # XPC:77: float64 divide, float32 store
+    assert (cpix < Hc * Wc).all() and (cpix[7] == -1).all()

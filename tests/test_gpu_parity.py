@@ -409,21 +409,25 @@ def test_gather_from_source_pixels_equals_gather_of_stored_colours():
     assert (b[1] == 0).all() and a[0].any()
 
 
-def test_frame_pipeline_vs_oracle_config1():
-    """BASELINE.json configs[0]: one 640x480 frame → crop → 1024-pt FPS (plus 2 more seeds)."""
+@pytest.mark.parametrize("dist_mode", [None, 0, 1])
+def test_frame_pipeline_vs_oracle_config1(dist_mode):
+    """BASELINE.json configs[0]: one 640x480 frame → crop → 1024-pt FPS (plus 2 more seeds).  dist_mode None = the
+    pipeline's default, which is the reference's use_cuda=True arithmetic (mode 1, DP3:47)."""
     intr = bench_intr()
     seeds = (0, 1, 2)
     frames = [synth_frame(s) for s in seeds]
     p = _ffi.make_params(intr, intr, apply_crop=True)
     po = cbind.make_params(intr, intr, apply_crop=1)
-    pipe = ops.FramePipeline(len(seeds), 480, 640, 1024, p, DEV)
+    pipe = ops.FramePipeline(len(seeds), 480, 640, 1024, p, DEV, dist_mode=dist_mode)
+    want_mode = 1 if dist_mode is None else dist_mode
+    assert pipe.fps.dist_mode == want_mode
     depth = dev(np.stack([f[0] for f in frames]))
     rgb = dev(np.stack([f[1] for f in frames]))
     for _ in range(2):           # buffers are reused: the second run must give the same answer
         xyz, col, idx, off = pipe.run(depth, rgb)
         torch.cuda.synchronize()
         for b, (d, c) in enumerate(frames):
-            ref = cbind.frame_pipeline(d, c, po, 1024, 0)
+            ref = cbind.frame_pipeline(d, c, po, 1024, want_mode)
             assert int(off[b + 1] - off[b]) == ref["M"]
             np.testing.assert_array_equal(idx[b].cpu().numpy(), ref["idx"])
             np.testing.assert_array_equal(xyz[b].cpu().numpy(), ref["xyz"])
@@ -437,7 +441,7 @@ def test_frame_pipeline_vs_oracle_on_tabletop_scenes():
     frames = [synth.scene_frame(s) for s in (0, 5)]
     p = _ffi.make_params(intr, intr, apply_crop=True)
     po = cbind.make_params(intr, intr, apply_crop=1)
-    pipe = ops.FramePipeline(len(frames), 480, 640, 1024, p, DEV)
+    pipe = ops.FramePipeline(len(frames), 480, 640, 1024, p, DEV, dist_mode=0)
     xyz, col, idx, off = pipe.run(dev(np.stack([f[0] for f in frames])), dev(np.stack([f[1] for f in frames])))
     torch.cuda.synchronize()
     for b, (d, c) in enumerate(frames):

@@ -78,7 +78,7 @@ def test_frame_pipeline_with_undersized_capacity_reports_instead_of_faulting():
     refs = [cbind.frame_pipeline(d, c, po, 128, 0) for d, c in frames]
     counts = [r["M"] for r in refs]
     cap_pf = (counts[0] + counts[1] + counts[2] // 2) // 4 + 1      # room for two frames and a bit
-    pipe = ops.FramePipeline(4, 120, 160, 128, p, "cuda", cap_per_frame=cap_pf)
+    pipe = ops.FramePipeline(4, 120, 160, 128, p, "cuda", dist_mode=0, cap_per_frame=cap_pf)
     assert pipe.stage1.cap < sum(counts) and pipe.stage1.cap >= counts[0] + counts[1]
     depth = dev(np.stack([f[0] for f in frames])); rgb = dev(np.stack([f[1] for f in frames]))
     xyz, col, idx, off = pipe.run(depth, rgb)

@@ -45,6 +45,31 @@ def test_ply_empty_ascii_and_xyz_only(tmp_path):
         ply.read_point_cloud(str(tmp_path / "bad.ply"))
 
 
+def test_assign_contiguous_blocks_are_balanced_and_complete():
+    lengths = [300, 120, 299, 50, 280, 310, 5, 90]
+    for world in (1, 2, 3, 8, 11):
+        parts = shard.assign_contiguous(lengths, world)
+        assert len(parts) == world and sum(parts, []) == list(range(8))            # contiguous, in order, complete
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) <= sum(lengths) / world + max(lengths)
+    assert shard.assign_contiguous([], 2) == [[], []]
+    assert shard.assign_contiguous([300] * 100, 8) == [list(range(a, b)) for a, b in
+                                                       ((0, 12), (12, 25), (25, 37), (37, 50), (50, 62), (62, 75), (75, 87), (87, 100))]
+
+
+def test_sharded_writer_single_process_equals_write_array(tmp_path):
+    from pcp import zarr_store
+    rng = np.random.default_rng(4)
+    counts = [7, 0, 5, 12, 1]
+    blocks = {i: rng.normal(size=(n, 3, 6)).astype(np.float32) for i, n in enumerate(counts) if n}
+    shard.write_rows_sharded(str(tmp_path / "a"), blocks, counts, (3, 6), chunk_rows=10, threads=3)
+    zarr_store.write_array(str(tmp_path / "b"), np.concatenate([blocks[i] for i in sorted(blocks)]), (10, 3, 6), "<f4", threads=2)
+    for f in sorted(os.listdir(tmp_path / "b")):
+        assert (tmp_path / "a" / f).read_bytes() == (tmp_path / "b" / f).read_bytes(), f
+    with pytest.raises(ValueError):
+        shard.write_rows_sharded(str(tmp_path / "c"), {0: blocks[0][:3]}, counts, (3, 6))
+
+
 def test_assign_episodes_balanced_and_complete():
     lengths = [300, 120, 299, 50, 280, 310, 5, 90]
     parts = shard.assign_episodes(lengths, 3)
@@ -64,10 +89,25 @@ dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", ra
 lengths = [7, 3, 5, 4, 6]
 mine = shard.assign_episodes(lengths, 2)[dist.get_rank()]
 local = {i: np.full((lengths[i], 4, 6), float(i), np.float32) for i in mine}     # stands in for GPU results
-eps = shard.gather_episodes(local, len(lengths))
-data, ends = shard.stack_for_zarr(eps)
-assert ends.tolist() == [7, 10, 15, 19, 25] and data.shape == (25, 4, 6)
-assert all(np.all(data[(0 if i == 0 else ends[i-1]):ends[i]] == i) for i in range(5))
+eps = shard.gather_episodes(local, len(lengths))                                  # a gather to rank 0 only
+if dist.get_rank() == 0:
+    data, ends = shard.stack_for_zarr(eps)
+    assert ends.tolist() == [7, 10, 15, 19, 25] and data.shape == (25, 4, 6)
+    assert all(np.all(data[(0 if i == 0 else ends[i-1]):ends[i]] == i) for i in range(5))
+else:
+    assert eps is None
+# the sharded zarr writer: every rank writes the chunks its rows fill, rank 0 the straddling ones
+from pcp import zarr_store
+for tag, deal in (("c", shard.assign_contiguous), ("g", shard.assign_episodes)):
+    mine = deal(lengths, 2)[dist.get_rank()]
+    rng = np.random.default_rng(3)
+    blocks = [rng.normal(size=(n, 4, 6)).astype(np.float32) for n in lengths]
+    path = os.path.join(sys.argv[4], "arr_" + tag)
+    full, sent = shard.write_rows_sharded(path, {i: blocks[i] for i in mine}, lengths, (4, 6), chunk_rows=4, threads=2)
+    back, meta = zarr_store.read_array(path)
+    assert meta["shape"] == [25, 4, 6] and meta["chunks"] == [4, 4, 6]
+    np.testing.assert_array_equal(back, np.concatenate(blocks))
+    print("rank", sys.argv[3], tag, "chunks written here", full, "pieces sent", sent)
 dist.destroy_process_group()
 print("rank", sys.argv[3], "ok")
 '''
@@ -77,7 +117,7 @@ def test_sharded_gather_world_size_2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER)
     port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)],
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(tmp_path)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):

@@ -12,6 +12,7 @@ ap.add_argument("--frames", type=int, default=300)
 ap.add_argument("--K", type=int, nargs="+", default=[1024])
 ap.add_argument("--algo", type=int, default=2)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--dist-mode", type=int, default=1)
 ap.add_argument("--H", type=int, default=480); ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--f", type=float, default=605.0)
 ap.add_argument("--scene", choices=["random", "tabletop"], default="random")
@@ -26,7 +27,7 @@ torch.cuda.synchronize()
 total = int(off[-1]); xyz = out["xyz32"][:total].clone()
 print("frames", a.frames, "total pts", total, "mean", total / a.frames)
 for K in a.K:
-    plan = ops.Fps(a.frames, total, a.H * a.W, K, dev, 0, a.algo)
+    plan = ops.Fps(a.frames, total, a.H * a.W, K, dev, a.dist_mode, a.algo)
     plan.run(xyz, off); torch.cuda.synchronize()
     ts = []
     for _ in range(a.reps):

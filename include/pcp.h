@@ -216,7 +216,9 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *             2: exact bucket-pruned FPS (same indices, far fewer distance evaluations); its first
  *                rounds defer bucket updates when the batch is large enough for that to pay
  *             3: as 2 with the deferred rounds always on   4: as 2 with them always off
- *                (same indices either way; for tests and tuning)
+ *             5: as 2 with MULTI-PICK rounds (one workgroup round certifies up to four consecutive picks)
+ *             6: as 2 with one pick per round, whatever the batch size
+ *                (same indices in every case; 3-6 are for tests and tuning)
  * `total_pts` is the row count of xyz (and of the workspace).  `max_pts` is an upper bound on the
  * largest cloud (host-known, e.g. H*W): it decides which size-bucketed launch shapes run, never
  * the picks.
@@ -247,8 +249,14 @@ int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t tot
  * no hipMalloc / hipFree / allocating library call.  All calls on one GPU share that GPU's array: calls that
  * overlap on the same GPU (different streams or threads) race — serialise them.  Nothing has to be cleared
  * between calls (a launch rewrites every row it reads).
+ * The FIRST call on a device resolves the array's device address (hipGetSymbolAddress, which may also make the
+ * runtime load the code object that holds the 32 MiB array): make that call — or pcp_fps_static_prepare(), which does
+ * nothing else — once per device OUTSIDE graph capture, as a warm-up; every later call only enqueues kernels.
+ * A recorded graph that contains this call must not be replayed while another static call (eager or replayed) runs on
+ * the same GPU: they share the array.
  */
 #define PCP_FPS_STATIC_MAX_PTS 1600000
+int pcp_fps_static_prepare(void);   /* current device; PCP_OK or PCP_ERR_LAUNCH / PCP_ERR_NO_DEVICE */
 int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
                            int64_t max_pts, int K, int dist_mode, int algo,
                            int64_t* idx, float* out_xyz, int32_t* overflow, void* stream);

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpcp_oracle.so")
+_SO = os.environ.get("PCP_ORACLE_SO") or os.path.join(_HERE, "libpcp_oracle.so")   # override: the ASan build (Makefile)
 
 
 class Intr(C.Structure):

@@ -1623,6 +1623,12 @@ static_assert(((size_t)PCP_FPS_STATIC_MAX_PTS * 16 + 255) / 256 * 256 + ((size_t
                   <= PCP_FPS_STATIC_BYTES,
               "PCP_FPS_STATIC_MAX_PTS points must fit the static scratch array");
 
+extern "C" int pcp_fps_static_prepare(void)
+{
+    void* ws = nullptr;
+    return fps_static_scratch(&ws);
+}
+
 extern "C" int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, int B, int64_t total_pts,
                                       int64_t max_pts, int K, int dist_mode, int algo, int64_t* idx,
                                       float* out_xyz, int32_t* overflow, void* stream)

@@ -476,6 +476,9 @@ __global__ void __launch_bounds__(256)
 sor_stats(const double* __restrict__ avg, const long long* __restrict__ offsets, double std_ratio,
           double* __restrict__ stats)
 {
+    // 66,048 bytes of static LDS: more than the 64 KiB every gfx9 target before gfx950 allows — this library is built
+    // for gfx950 (160 KB of LDS per CU) only, see the Makefile
+    static_assert((SOR_ST_BLOCK + 2 * SOR_ST_GROUP) * sizeof(double) <= 160 * 1024, "sor_stats' addend buffer must fit gfx950's LDS");
     __shared__ double term_s[SOR_ST_BLOCK + 2 * SOR_ST_GROUP];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long lo = offsets[b], hi = offsets[b + 1];

@@ -11,7 +11,7 @@ EXPORTS = (
     "pcp_backproject_dense", "pcp_align_colors", "pcp_backproject_workspace_bytes", "pcp_backproject_align_crop",
     "pcp_backproject_align_crop_multicam", "pcp_depth_mm_to_m",
     "pcp_crop_mask", "pcp_crop_workspace_bytes", "pcp_crop_compact", "pcp_crop_compact_batched",
-    "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_fps_batched_static", "pcp_gather_rgb", "pcp_gather_rgb_pixels", "pcp_sampled_color_pixels", "pcp_pack_dp3",
+    "pcp_fps_workspace_bytes", "pcp_fps_batched", "pcp_fps_batched_static", "pcp_fps_static_prepare", "pcp_gather_rgb", "pcp_gather_rgb_pixels", "pcp_sampled_color_pixels", "pcp_pack_dp3",
     "pcp_voxel_workspace_bytes", "pcp_voxel_downsample", "pcp_sor_workspace_bytes", "pcp_statistical_outlier_removal",
 )
 
@@ -83,6 +83,7 @@ def load_library():
     L.pcp_fps_batched.restype = i32
     L.pcp_fps_batched_static.argtypes = [vp, vp, i32, i64, i64, i32, i32, i32, vp, vp, vp, vp]
     L.pcp_fps_batched_static.restype = i32
+    L.pcp_fps_static_prepare.argtypes = []; L.pcp_fps_static_prepare.restype = i32
     L.pcp_gather_rgb.argtypes = [vp, vp, i64, vp, i32, i32, i32, vp, vp]; L.pcp_gather_rgb.restype = i32
     L.pcp_gather_rgb_pixels.argtypes = [vp, vp, i32, i32, i32, i32, i32, pp, vp, vp, i64, vp, i32, i32, vp, vp]
     L.pcp_gather_rgb_pixels.restype = i32

@@ -29,7 +29,8 @@ class SyntheticEpisodes:
         return depth, rgb, state, action
 
 
-def run(source, out_zarr, K=1024, chunk=100, device=None, compressor="zlib", threads=8, rgb_on_host=True, params=None):
+def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", threads=None, rgb_on_host=True, params=None,
+        prefetch=4, warmup=True):
     """Stream every episode of `source` this rank owns through the GPU path and assemble the store.
     Returns dict(frames, episodes, seconds by phase, rates) — this rank's view; frames / episodes are global."""
     import torch
@@ -40,18 +41,47 @@ def run(source, out_zarr, K=1024, chunk=100, device=None, compressor="zlib", thr
     if device is None:
         device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % ndev}"     # rehearsals with more ranks than GPUs share devices
     torch.cuda.set_device(torch.device(device))
+    if threads is None:
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))       # the GPU box gives one rank 16 CPUs
     p = params if params is not None else _ffi.make_params(source.intr, source.intr, apply_crop=True)
     runner = EpisodeRunner(source.H, source.W, K, p, device=device, chunk=chunk, depth_mm=source.depth_mm,
                            rgb_on_host=rgb_on_host, profile=True)
+    if warmup:                                                  # first-touch of the pinned buffers, lazy module loads
+        z = np.zeros((min(chunk, 8), source.H, source.W), np.uint16 if source.depth_mm else np.float32)
+        runner.run_arrays(z, np.zeros(z.shape + (3,), np.uint8))
+        for k in runner.stats:
+            runner.stats[k] = 0 if isinstance(runner.stats[k], int) else 0.0
     t = dict(source_s=0.0, runner_s=0.0)
-
-    def produce(ep):
+    from . import shard
+    _, rank, world = shard._dist()
+    mine = shard.assign_contiguous(source.lengths, world)[rank]        # the same deal assemble() makes
+    ddt = np.uint16 if source.depth_mm else np.float32
+    ready = {}
+    # Episodes are loaded a few at a time and streamed through the runner BACK TO BACK (one chunk stream, no drain at
+    # episode boundaries: the upload of an episode's first chunk overlaps the kernels of the previous episode's last).
+    for g0 in range(0, len(mine), max(1, int(prefetch))):
+        group = mine[g0:g0 + max(1, int(prefetch))]
         t0 = time.perf_counter()
-        depth, rgb, state, action = source.load(ep)
+        loaded = [source.load(ep) for ep in group]
         t1 = time.perf_counter()
-        rows, counts = runner.run_arrays(depth, rgb)
+
+        def chunks():
+            for depth, rgb, _, _ in loaded:
+                for i in range(0, depth.shape[0], chunk):
+                    yield (np.ascontiguousarray(depth[i:i + chunk], dtype=ddt), np.ascontiguousarray(rgb[i:i + chunk], dtype=np.uint8))
+
+        rows, counts = runner.run_chunks(chunks())
         t["source_s"] += t1 - t0
         t["runner_s"] += time.perf_counter() - t1
+        at = 0
+        for ep, (depth, _, state, action) in zip(group, loaded):
+            n = depth.shape[0]
+            ready[ep] = (rows[at:at + n], counts[at:at + n], state, action)
+            at += n
+        del loaded
+
+    def produce(ep):
+        rows, counts, state, action = ready.pop(ep)
         if (np.asarray(counts) == 0).any():                       # the reference's filter step dies on an empty crop (S2:15-18)
             print(f"Warning: episode {ep} has a frame with no point inside the workspace. Skipping.")
             return None
@@ -62,7 +92,7 @@ def run(source, out_zarr, K=1024, chunk=100, device=None, compressor="zlib", thr
     timing = {}
     t0 = time.perf_counter()
     frames, episodes = build_zarr.assemble(source.lengths, produce, out_zarr, compressor, threads, timing)
-    wall = time.perf_counter() - t0
+    wall = time.perf_counter() - t0 + t["source_s"] + t["runner_s"]
     runner.close()
     st = runner.stats
     mine = st["frames"]

@@ -41,8 +41,9 @@ class EpisodeRunner:
         self.d_depth_m = torch.empty((self.chunk, H, W), dtype=torch.float32, device=self.dev) if self.depth_mm else None
         if self.rgb_on_host:
             self.h_rgb = self.d_rgb = None
-            self.h_xyz = mk((self.chunk, K, 3), torch.float32)
-            self.h_cpix = mk((self.chunk, K), torch.int32)
+            self.h_xyz = [mk((self.chunk, K, 3), torch.float32) for _ in range(2)]
+            self.h_cpix = [mk((self.chunk, K), torch.int32) for _ in range(2)]
+            self.h_rows = None
         else:
             self.h_rgb = [mk((self.chunk, self.Hc, self.Wc, 3), torch.uint8) for _ in range(2)]
             self.d_rgb = [torch.empty((self.chunk, self.Hc, self.Wc, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
@@ -51,10 +52,12 @@ class EpisodeRunner:
         self._ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(2)] if self.profile else None
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
-        self.h_rows = mk((self.chunk, K, 6), torch.float32)
-        self.h_off = mk((self.chunk + 1,), torch.int64)
-        self.h_flags = mk((2,), torch.int32)                 # stage-1 capacity / FPS bounds flags of the chunk
-        self.done = torch.cuda.Event()
+        if not self.rgb_on_host:
+            self.h_rows = [mk((self.chunk, K, 6), torch.float32) for _ in range(2)]
+        self.h_off = [mk((self.chunk + 1,), torch.int64) for _ in range(2)]
+        self.h_flags = [mk((2,), torch.int32) for _ in range(2)]      # stage-1 capacity / FPS bounds flags of the chunk
+        self.done = [torch.cuda.Event() for _ in range(2)]
+        self._collector = ThreadPoolExecutor(max_workers=1)
         self.stage_threads = max(1, int(stage_threads))
         self.upload_piece = int(upload_piece)                # frames per staging/DMA piece
         self._pool = ThreadPoolExecutor(max_workers=self.stage_threads) if self.stage_threads > 1 else None
@@ -64,6 +67,9 @@ class EpisodeRunner:
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        if getattr(self, "_collector", None) is not None:
+            self._collector.shutdown(wait=True)
+            self._collector = None
 
     def __del__(self):
         try:
@@ -87,6 +93,7 @@ class EpisodeRunner:
         """Stage + upload one chunk in pieces: while the DMA engine moves piece i, the host threads stage piece
         i+1 into the pinned buffer, so staging and the PCIe transfer overlap instead of adding up."""
         n = depth.shape[0]
+        self.uploaded[slot].synchronize()                    # the slot's pinned staging buffer: its last H2D has finished
         if n < self.chunk:                                   # a short tail chunk: invalid depth → empty clouds
             self.h_depth[slot][n:].zero_()
         piece = max(1, self.upload_piece)
@@ -124,81 +131,102 @@ class EpisodeRunner:
         with torch.cuda.device(self.dev):                    # events, streams and kernels all belong to self.dev
             return self._run_chunks(chunks)
 
-    def _host_rows(self, n, rgb):
+    def _host_rows(self, slot, n, rgb):
         """(n,K,6) DP3 rows from the chunk's xyz + colour pixels and the HOST rgb images: colours[mask] = rgb[v_idx,
         u_idx] / 255 (XPC:77), zero where masked (XPC:76), times 255 again in the row (CHK:141) = the u8 value."""
         out = np.empty((n, self.K, 6), np.float32)
-        out[:, :, :3] = self.h_xyz[:n].numpy()
-        cp = self.h_cpix[:n].numpy()
-        flat = np.ascontiguousarray(rgb[:n]).reshape(n, self.Hc * self.Wc, 3)
-        got = np.take_along_axis(flat, np.maximum(cp, 0)[:, :, None].astype(np.int64), axis=1)
-        out[:, :, 3:] = got
-        out[:, :, 3:][cp < 0] = 0.0
+        xyz, cp, hw = self.h_xyz[slot].numpy(), self.h_cpix[slot].numpy(), self.Hc * self.Wc
+
+        def part(ab):                                   # frames [a, b): numpy's take releases the GIL
+            a, b = ab
+            out[a:b, :, :3] = xyz[a:b]
+            c = cp[a:b]
+            flat = np.ascontiguousarray(rgb[a:b]).reshape((b - a) * hw, 3)
+            rows = np.maximum(c, 0).astype(np.int64)
+            rows += (np.arange(b - a, dtype=np.int64) * hw)[:, None]
+            got = flat[rows.reshape(-1)].reshape(b - a, self.K, 3)     # one row gather: (b-a)*K pixels of 3 bytes
+            np.multiply(got, (c >= 0)[:, :, None], out=out[a:b, :, 3:], casting="unsafe")
+
+        parts = min(self.stage_threads, n) if self._pool is not None else 1
+        if parts <= 1:
+            part((0, n))
+        else:
+            cuts = [n * i // parts for i in range(parts + 1)]
+            list(self._pool.map(part, zip(cuts[:-1], cuts[1:])))
         return out
 
-    def _run_chunks(self, chunks):
+    def _collect(self, slot, n, rgb, chunk_no):
+        """Collector thread: wait for chunk `chunk_no`'s results (pinned buffers of `slot`) and turn them into rows
+        while the GPU works on the next chunk."""
         import time
-        rows, counts = [], []
+        t0 = time.perf_counter()
+        self.done[slot].synchronize()
+        t1 = time.perf_counter()
+        fl = self.h_flags[slot]
+        if int(fl[0]) or int(fl[1]):
+            raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if int(fl[0]) else
+                                "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
+        rows = self._host_rows(slot, n, rgb) if self.rgb_on_host else self.h_rows[slot][:n].numpy().copy()
+        counts = np.diff(self.h_off[slot].numpy())[:n]
+        st = self.stats
+        st["wait_s"] += t1 - t0; st["host_rows_s"] += time.perf_counter() - t1
+        st["frames"] += n; st["chunks"] += 1
+        if self.profile:                                    # the chunk's events have all completed by now
+            ev = self._ev[slot]
+            st["h2d_ms"] += ev[0].elapsed_time(ev[1]); st["kernels_ms"] += ev[2].elapsed_time(ev[3])
+            st["d2h_ms"] += ev[3].elapsed_time(ev[4])
+        return rows, counts
+
+    def _run_chunks(self, chunks):
+        """Three things overlap: the GPU runs chunk i, the main thread stages + uploads chunk i+1 (copy stream), the
+        collector thread turns chunk i-1's results into rows.  Every buffer exists twice (slot = chunk parity)."""
+        futures = []
         main = torch.cuda.current_stream(self.dev)
         for s in range(2):
             self.consumed[s].record(main)
         it = iter(chunks)
         nxt = next(it, None)
-        slot = 0
+        i = 0
         if nxt is not None:
-            self._upload(slot, *nxt)
+            self._upload(0, *nxt)
         while nxt is not None:
-            cur_n, cur_slot = nxt[0].shape[0], slot
-            main.wait_event(self.uploaded[cur_slot])
-            ev = self._ev[cur_slot] if self.profile else None
+            cur_n, slot = nxt[0].shape[0], i & 1
+            main.wait_event(self.uploaded[slot])
+            ev = self._ev[slot] if self.profile else None
             if ev:
                 ev[2].record(main)
-            dsrc = ops.depth_mm_to_m(self.d_depth[cur_slot], self.d_depth_m) if self.depth_mm else self.d_depth[cur_slot]
+            dsrc = ops.depth_mm_to_m(self.d_depth[slot], self.d_depth_m) if self.depth_mm else self.d_depth[slot]
             if self.rgb_on_host:
-                cur_rgb = nxt[1]                                 # stays on the host; read again when the pixels are known
                 xyz, cpix, idx, off = self.pipe.run_host_rgb(dsrc, self.Hc, self.Wc)
-                self.consumed[cur_slot].record(main)
+                self.consumed[slot].record(main)
                 if ev:
                     ev[3].record(main)
-                self.h_xyz.copy_(xyz, non_blocking=True)
-                self.h_cpix.copy_(cpix, non_blocking=True)
+                self.h_xyz[slot].copy_(xyz, non_blocking=True)
+                self.h_cpix[slot].copy_(cpix, non_blocking=True)
             else:
-                xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[cur_slot])
+                xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[slot])
                 packed = ops.pack_dp3(xyz, col)
-                self.consumed[cur_slot].record(main)
+                self.consumed[slot].record(main)
                 if ev:
                     ev[3].record(main)
-                self.h_rows.copy_(packed, non_blocking=True)
-            self.h_off.copy_(off, non_blocking=True)
-            self.h_flags[0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
-            self.h_flags[1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
+                self.h_rows[slot].copy_(packed, non_blocking=True)
+            self.h_off[slot].copy_(off, non_blocking=True)
+            self.h_flags[slot][0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
+            self.h_flags[slot][1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
             if ev:
                 ev[4].record(main)
-            self.done.record(main)
+            self.done[slot].record(main)
+            futures.append(self._collector.submit(self._collect, slot, cur_n, nxt[1] if self.rgb_on_host else None, i))
             nxt = next(it, None)
+            i += 1
             if nxt is not None:
-                slot ^= 1
-                self._upload(slot, *nxt)
-            t0 = time.perf_counter()
-            self.done.synchronize()
-            t1 = time.perf_counter()
-            if int(self.h_flags[0]) or int(self.h_flags[1]):
-                raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if int(self.h_flags[0]) else
-                                    "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
-            if self.rgb_on_host:
-                rows.append(self._host_rows(cur_n, cur_rgb))
-            else:
-                rows.append(self.h_rows[:cur_n].numpy().copy())
-            counts.append(np.diff(self.h_off.numpy())[:cur_n])
-            st = self.stats
-            st["wait_s"] += t1 - t0; st["host_rows_s"] += time.perf_counter() - t1
-            st["frames"] += cur_n; st["chunks"] += 1
-            if ev:                                              # the chunk's events have all completed by now
-                st["h2d_ms"] += ev[0].elapsed_time(ev[1]); st["kernels_ms"] += ev[2].elapsed_time(ev[3])
-                st["d2h_ms"] += ev[3].elapsed_time(ev[4])
-        if not rows:
+                if i >= 2:
+                    futures[i - 2].result()                      # the slot's pinned buffers and events are free again
+                self._upload(i & 1, *nxt)
+        if not futures:
             return np.zeros((0, self.K, 6), np.float32), np.zeros((0,), np.int64)
-        return np.concatenate(rows), np.concatenate(counts)
+        got = [f.result() for f in futures]
+        return np.concatenate([g[0] for g in got]), np.concatenate([g[1] for g in got])
 
     def run_arrays(self, depth, rgb):
         T = depth.shape[0]

@@ -30,11 +30,11 @@ def make_cloud(rng, m):
     return np.ascontiguousarray(p, np.float64)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     rng = np.random.default_rng(a.seed)
     t_end, n = time.time() + a.seconds, 0
     stats = {"voxel_clouds": 0, "voxel_clamped": 0, "sor_clouds": 0, "sor_refused": 0, "sor_overflow": 0}

@@ -2,7 +2,7 @@
 """Randomised FPS parity soak (not collected by pytest; run by hand on a GPU box):
    python tests/stress_fps.py [--seconds 150] [--seed 0]
 Random batches of clouds (sizes on both sides of every launch-shape bound, volumes, sheets, lattices with exact
-ties, duplicates), random K, distance mode and algo 2/3/4, each cloud checked bit-exact against the C oracle."""
+ties, duplicates), random K, distance mode and algo 2/3/4/5/6 (deferred rounds on / off, multi-pick rounds on / off), each cloud checked bit-exact against the C oracle."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]
@@ -29,11 +29,11 @@ def make_cloud(rng, m):
     return (rng.standard_normal((m, 3)) * np.array([1.0, 0.2, 0.01])).astype(np.float32)   # rod-ish
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150)
     ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     rng = np.random.default_rng(a.seed)
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 1000, 2047, 2048, 2049, 5000, 20000, 65535, 65536, 65537, 90000,
              131072, 131073, 200000, 262144, 262145, 300000]
@@ -46,7 +46,7 @@ def main():
             ms += [int(rng.integers(2048, 6000)) for _ in range(200)]
         clouds = [make_cloud(rng, m) for m in ms]
         K = int(rng.choice([1, 2, 5, 64, 255, 256, 257, 300, 700, 1024, 1500]))
-        dm, algo = int(rng.integers(0, 2)), int(rng.choice([2, 3, 4]))
+        dm, algo = int(rng.integers(0, 2)), int(rng.choice([2, 3, 4, 5, 6]))
         off = np.zeros(len(clouds) + 1, np.int64); off[1:] = np.cumsum([len(c) for c in clouds])
         xyz, idx = ops.fps_batched(torch.from_numpy(np.concatenate(clouds)).cuda(), torch.from_numpy(off).cuda(), K,
                                    dist_mode=dm, algo=algo, max_pts=max(ms))

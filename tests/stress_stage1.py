@@ -17,11 +17,11 @@ def rot(rng):
     return q * np.sign(np.linalg.det(q))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     rng = np.random.default_rng(a.seed)
     t_end, n = time.time() + a.seconds, 0
     while time.time() < t_end:

@@ -107,7 +107,7 @@ def test_rgb_stays_on_the_host_and_the_rows_are_the_same():
     ci = dict(fx=66.0, fy=56.0, cx=Wc / 2 - 1.5, cy=Hc / 2 + 0.75)
     rng = np.random.default_rng(21)
     mm = rng.integers(300, 1500, (T, H, W)).astype(np.uint16)
-    mm[3, 10:, :] = 0                                                  # a sparse frame: fewer than K survivors
+    mm[3, 5:, :] = 0                                                   # a sparse frame: fewer than K survivors
     mm[7] = 0                                                          # an empty one
     rgb = rng.integers(0, 256, (T, Hc, Wc, 3), dtype=np.uint8)
     depth = mm.astype(np.float32) / 1000.0

@@ -1,6 +1,8 @@
 """GPU (-m gpu): the C ABI only enqueues on the caller's stream — no allocation, no synchronisation — so a whole step
-(stage 1, both scans, scatter, every FPS launch shape, colour gather) can be recorded into a HIP graph and replayed on
-new input.  Checked bit for bit against the same step run eagerly."""
+(stage 1, both scans, scatter, FPS, colour gather) can be recorded into a HIP graph and replayed on new input, checked
+bit for bit against the same step run eagerly.  The frame-pipeline test records the 64-row wide FPS shape only (its
+clouds are small); test_every_fps_launch_shape_records_into_a_hip_graph records the halved / quartered-bucket and the
+deep shape too, including the hipFuncSetAttribute call the deep shape makes under capture."""
 import numpy as np
 import pytest
 import torch
@@ -71,6 +73,7 @@ def test_static_entry_point_records_into_a_hip_graph():
     out = torch.zeros((1, K, 3), dtype=torch.float32, device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     p = lambda t: C.c_void_p(t.data_ptr())
+    assert L.pcp_fps_static_prepare() == 0                  # resolve the static array's address OUTSIDE the capture (pcp.h)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -86,3 +89,36 @@ def test_static_entry_point_records_into_a_hip_graph():
         torch.cuda.synchronize()
         assert int(flag) == 0
         assert torch.equal(idx, ref.idx) and torch.equal(out, ref.xyz)
+
+
+def test_every_fps_launch_shape_records_into_a_hip_graph():
+    """max_pts > 262,144 makes pcp_fps_batched launch all four bucket shapes (wide, halved, quartered buckets, deep — the
+    deep one raises its dynamic-LDS limit with hipFuncSetAttribute on every launch): record them, replay on other clouds
+    of the same sizes, compare with the eager call."""
+    rng = np.random.default_rng(9)
+    sizes = [3000, 70000, 140000, 270000, 64]
+    K = 96
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).cuda()
+    total = int(sum(sizes))
+    sets = [np.concatenate([rng.uniform(-1, 1, (m, 3)) * rng.uniform(0.2, 1.0, 3) for m in sizes]).astype(np.float32)
+            for _ in range(2)]
+    xyz = torch.from_numpy(sets[0]).cuda()
+    plan = ops.Fps(len(sizes), total, 300000, K, "cuda", 1, 0)
+    refs = []
+    for s_ in sets:
+        xyz.copy_(torch.from_numpy(s_))
+        plan.run(xyz, off)
+        torch.cuda.synchronize()
+        assert int(plan.overflow) == 0
+        refs.append((plan.idx.clone(), plan.xyz.clone()))
+    assert not torch.equal(refs[0][0], refs[1][0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        plan.run(xyz, off)
+    for it in (0, 1, 0):
+        xyz.copy_(torch.from_numpy(sets[it]))
+        plan.idx.fill_(-7); plan.xyz.fill_(-7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(plan.overflow) == 0
+        assert torch.equal(plan.idx, refs[it][0]) and torch.equal(plan.xyz, refs[it][1]), f"replay on set {it}"

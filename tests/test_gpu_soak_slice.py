@@ -1,0 +1,80 @@
+"""GPU (-m gpu): a seeded slice of the randomised soaks (tests/stress_fps.py, stress_stage1.py, stress_filters.py — run by
+hand for minutes on the MI355X) inside the driver's own run: a few seconds each, fixed seeds, every case bit-exact
+against the C oracle, plus a deterministic sweep over the FPS launch-shape bounds."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cbind
+from pcp import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _no_mismatch(mod, seconds, seed, capsys):
+    try:
+        mod.main(["--seconds", str(seconds), "--seed", str(seed)])
+    except SystemExit as e:                                # the soak exits 1 on the first mismatch, after printing it
+        pytest.fail(f"{mod.__name__} seed {seed}: {capsys.readouterr().out[-400:]} (exit {e.code})")
+    out = capsys.readouterr().out
+    assert "all bit-exact" in out or "done" in out, out[-300:]
+    return out
+
+
+def test_fps_launch_shape_bounds_both_modes_every_algo():
+    """Clouds one point below, on and above every size bound of the FPS launch shapes (2,048 brute/bucket; 65,536 /
+    131,072 / 262,144 wide / halved / quartered / deep buckets), every cloud kind of the soak, both distance modes, the
+    deferred rounds forced on and off (algo 3 / 4) and the multi-pick rounds forced on and off (algo 5 / 6)."""
+    import stress_fps
+    rng = np.random.default_rng(20261111)
+    bounds = [2048, 65536, 131072, 262144]
+    case = 0
+    for bound in bounds:
+        for m in (bound - 1, bound, bound + 1):
+            cloud = stress_fps.make_cloud(rng, m)
+            for K in (33, 150):
+                dm, algo = case & 1, (2, 3, 4, 5, 6)[case % 5]
+                case += 1
+                off = torch.tensor([0, m], dtype=torch.int64, device="cuda")
+                xyz, idx = ops.fps_batched(torch.from_numpy(cloud).cuda(), off, K, dist_mode=dm, algo=algo, max_pts=m)
+                rx, ri = cbind.fps(cloud, K, dm)
+                np.testing.assert_array_equal(idx[0].cpu().numpy(), ri, err_msg=f"M={m} K={K} mode={dm} algo={algo}")
+                np.testing.assert_array_equal(xyz[0].cpu().numpy(), rx)
+    assert case == 24
+
+
+def test_fps_multi_pick_rounds_equal_the_sequential_picks_on_batches():
+    """algo 5 (up to four certified picks per round) against the oracle on ragged batches: volumes, sheets, lattices with
+    exact ties, heavy duplicates, clusters, rods; K up to the reference's 2,500."""
+    import stress_fps
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        ms = [int(rng.choice([1, 2, 63, 64, 65, 1000, 2049, 5000, 20000, 61000])) for _ in range(5)]
+        clouds = [stress_fps.make_cloud(rng, m) for m in ms]
+        K = (64, 300, 1024, 2500, 257, 700)[trial]
+        dm = trial & 1
+        off = np.zeros(len(ms) + 1, np.int64); off[1:] = np.cumsum(ms)
+        xyz, idx = ops.fps_batched(torch.from_numpy(np.concatenate(clouds)).cuda(), torch.from_numpy(off).cuda(), K,
+                                   dist_mode=dm, algo=5, max_pts=max(ms))
+        for b, c in enumerate(clouds):
+            rx, ri = cbind.fps(c, K, dm)
+            np.testing.assert_array_equal(idx[b].cpu().numpy(), ri, err_msg=f"trial {trial} cloud {b} M={ms[b]} K={K}")
+            np.testing.assert_array_equal(xyz[b].cpu().numpy(), rx)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fps_soak_slice(seed, capsys):
+    import stress_fps
+    _no_mismatch(stress_fps, 4, seed, capsys)
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_stage1_soak_slice(seed, capsys):
+    import stress_stage1
+    _no_mismatch(stress_stage1, 5, seed, capsys)
+
+
+@pytest.mark.parametrize("seed", [31])
+def test_filters_soak_slice(seed, capsys):
+    import stress_filters
+    _no_mismatch(stress_filters, 5, seed, capsys)

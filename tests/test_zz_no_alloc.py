@@ -43,6 +43,17 @@ def test_static_entry_point_equals_the_workspace_one_twice_in_a_row():
     first = _call_both(big, 300, 1, 0)                                       # wide, split-bucket and brute... shapes
     assert first[0, 0] == 0 and (first[3] == -1).all()
     _call_both(small, 300, 1, 0)                                             # smaller input over the first call's leftovers
+    # ... and it really allocates nothing: device memory in use is the same before and after a call
+    xyz = torch.from_numpy(np.concatenate(small)).cuda()
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum([c.shape[0] for c in small])]).astype(np.int64)).cuda()
+    idx = torch.empty((3, 64), dtype=torch.int64, device="cuda"); flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rc = L.pcp_fps_batched_static(C.c_void_p(xyz.data_ptr()), C.c_void_p(off.data_ptr()), 3, xyz.shape[0], 40000, 64, 1, 0,
+                                  C.c_void_p(idx.data_ptr()), None, C.c_void_p(flag.data_ptr()),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.cuda.mem_get_info()[0] == free0
     _call_both(small, 128, 0, 1)                                             # brute-force path uses the array too
     _call_both(big, 64, 0, 3)
     # beyond the static array: a clear error, nothing launched, outputs untouched

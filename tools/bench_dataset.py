@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--episodes", type=int, default=6)
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--K", type=int, default=1024)
-    ap.add_argument("--chunk", type=int, default=100)
+    ap.add_argument("--chunk", type=int, default=150)
     ap.add_argument("--H", type=int, default=480)
     ap.add_argument("--W", type=int, default=640)
     ap.add_argument("--out", required=True)

@@ -86,7 +86,7 @@ def _read_rgb(path):
     return np.asarray(Image.open(path).convert("RGB"))             # == cv2.imread + BGR2RGB (XPC:103)
 
 
-def process(bag_path, extracted_data_root, output_root, base_to_ext_cam):
+def process(bag_path, extracted_data_root, output_root, base_to_ext_cam, io_threads=8):
     """XPC:80-125."""
     intr = extract_intrinsics(bag_path, extracted_data_root)
     for sub in ("camera_frame", "global_frame"):
@@ -103,23 +103,42 @@ def process(bag_path, extracted_data_root, output_root, base_to_ext_cam):
     dev = _device()
     p = _params(intr["depth"], intr["color"], T_DEPTH_TO_COLOR, base_to_ext_cam)
     plan, done = None, 0
-    for b0 in range(0, len(frames), BATCH):
-        ids = frames[b0:b0 + BATCH]
-        depth = np.stack([np.load(os.path.join(depth_path, f"depth_{i:05d}.npy")).astype(np.float32) for i in ids])
-        rgb = np.stack([_read_rgb(os.path.join(rgb_path, f"rgb_{i:05d}.png")) for i in ids])
-        B, H, W = depth.shape
-        if plan is None or (plan.B, plan.H, plan.W) != (B, H, W):
-            plan = ops.Stage1(B, H, W, dev, want=("xyz_cam64", "xyz64", "rgb32"))
-        out, off = plan.run(torch.from_numpy(depth).to(dev), torch.from_numpy(rgb).to(dev), p)
-        off = off.cpu().numpy()
-        cam, glob, col = (out[k][:off[-1]].cpu().numpy() for k in ("xyz_cam64", "xyz64", "rgb32"))
-        for j, i in enumerate(ids):
-            sl = slice(off[j], off[j + 1])
-            ply.write_point_cloud(os.path.join(output_root, "camera_frame", f"pc_{i:05d}.ply"), cam[sl], col[sl])
-            ply.write_point_cloud(os.path.join(output_root, "global_frame", f"pc_{i:05d}.ply"), glob[sl], col[sl])
-            done += 1
-            if (i + 1) % 50 == 0:
-                print(f"  Processed {i + 1} frames...")
+
+    def load(i):                                                   # XPC:103-104
+        return (np.load(os.path.join(depth_path, f"depth_{i:05d}.npy")).astype(np.float32),
+                _read_rgb(os.path.join(rgb_path, f"rgb_{i:05d}.png")))
+
+    def write_pair(i, cam, glob, col):                             # XPC:113-123
+        ply.write_point_cloud(os.path.join(output_root, "camera_frame", f"pc_{i:05d}.ply"), cam, col)
+        ply.write_point_cloud(os.path.join(output_root, "global_frame", f"pc_{i:05d}.ply"), glob, col)
+
+    # The reference's loop is serial (XPC:96-125).  Here the files of batch b+1 are decoded and the PLYs of batch b-1
+    # written by a thread pool while the GPU handles batch b; outputs are the same files, byte for byte.
+    from concurrent.futures import ThreadPoolExecutor
+    batches = [frames[b0:b0 + BATCH] for b0 in range(0, len(frames), BATCH)]
+    with ThreadPoolExecutor(max_workers=max(1, int(io_threads))) as pool:
+        loads = [pool.submit(load, i) for i in batches[0]] if batches else []
+        writes = []
+        for bi, ids in enumerate(batches):
+            got = [f.result() for f in loads]
+            loads = [pool.submit(load, i) for i in batches[bi + 1]] if bi + 1 < len(batches) else []
+            depth = np.stack([g[0] for g in got]); rgb = np.stack([g[1] for g in got])
+            B, H, W = depth.shape
+            if plan is None or (plan.B, plan.H, plan.W) != (B, H, W):
+                plan = ops.Stage1(B, H, W, dev, want=("xyz_cam64", "xyz64", "rgb32"))
+            out, off = plan.run(torch.from_numpy(depth).to(dev), torch.from_numpy(rgb).to(dev), p)
+            off = off.cpu().numpy()
+            cam, glob, col = (out[k][:off[-1]].cpu().numpy() for k in ("xyz_cam64", "xyz64", "rgb32"))
+            for f in writes:
+                f.result()                                         # the previous batch is on disk (and its errors raised)
+            writes = [pool.submit(write_pair, i, cam[off[j]:off[j + 1]], glob[off[j]:off[j + 1]], col[off[j]:off[j + 1]])
+                      for j, i in enumerate(ids)]
+            for i in ids:
+                done += 1
+                if (i + 1) % 50 == 0:
+                    print(f"  Processed {i + 1} frames...")
+        for f in writes:
+            f.result()
     return done
 
 

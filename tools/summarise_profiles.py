@@ -17,7 +17,7 @@ if ks:
 
 OURS = ("fps_", "k1_", "pcp_", "crop_", "gather", "pack", "sor_", "vox_", "rocprim")
 acc = defaultdict(lambda: defaultdict(list))
-for sub in ("fetch", "write", "sq", "sq2"):
+for sub in ("fetch", "write", "sq", "sq2", "l2"):
     for f in glob.glob(os.path.join(out, sub, "**", "*_counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
@@ -41,4 +41,13 @@ if fps:
                        "of 16 B/lane coalesced reads, so reads are counted as 2 x FETCH_SIZE; KB = 1024 B; "
                        "Infinity-Cache hits are included in these fabric-side counters",
                "frames_per_launch": 300}, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+l2 = {k: {c: v[c]["mean_per_dispatch"] for c in ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum") if c in v} for k, v in pmc.items()}
+l2 = {k: v for k, v in l2.items() if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v}
+for v in l2.values():
+    tot = v["TCC_HIT_sum"] + v["TCC_MISS_sum"]
+    v["l2_hit_rate"] = v["TCC_HIT_sum"] / tot if tot else None
+    v["miss_bytes_at_128B"] = v["TCC_MISS_sum"] * 128
+if l2:
+    json.dump({"command": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -- python3 bench.py --steps 2 --warmup 1 (own pass)",
+               "mean_per_dispatch": l2}, open(os.path.join(dst, f"{tag}_l2.json"), "w"), indent=1, sort_keys=True)
 print("summarised", sorted(pmc))

@@ -788,11 +788,283 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
     __syncthreads();                                            // the eager loop restarts the partials' parity
 }
 
+// ---- multi-pick rounds ----------------------------------------------------------------------------------------------
+// One workgroup round applies the n <= 4 newest samples to every bucket any of them could change (one pass over a bucket's
+// rows for all of them) and then certifies up to four further picks at once:
+//   every wave publishes its best point (key, xyz) and `rub`, an upper bound of every OTHER min-distance it owns (the
+//   second-largest value of the multiset {bucket top, bucket runner-up} over its buckets).  Let a1 > a2 > ... be the
+//   wave tops in key order, from waves w1, w2, ...  a1 is the next pick, as ever.  a_i is certainly the pick after
+//   a_(i-1) when for every earlier pick a_j of this round
+//       rub(w_j) < value(a_i)             nothing else in an earlier winner's wave can overtake a_i,
+//       !(dist2(a_j, a_i) < value(a_i))   applying a_j leaves a_i's min-distance as it is,
+//       a_j is finite                     its own min-distance drops to 0 once it is applied,
+//   and value(a_i) differs from every other wave top (a tie on the value is resolved by index order, by a later round's
+//   first pick): all other points only lose min-distance, so a_i stays the arg-max.
+// min() is exact and commutative, so applying a round's samples together leaves the same min-distances as applying them
+// one by one; a bucket test against the older, larger bucket maximum only streams a superset.  The picks are therefore
+// the sequential ones, in order — in a third of the workgroup rounds on the bench clouds
+// (tests/model_fps_multipick.py: 350 rounds for 1,023 picks).
+// Instruction diet (a round keeps all sixteen waves busy, so it is bound by instruction issue, not by its chain):
+//   * a streamed bucket is REDUCED only if a sample lowers the min-distance of its arg-max row (bxyz[j]): otherwise its
+//     key cannot change (every other row only loses min-distance); its runner-up value may go stale-high, which is safe;
+//   * a row is updated only with the samples whose test the bucket failed (per-bucket sample bits);
+//   * a wave rebuilds its partial only when a reduced bucket could be its top or runner-up (old key >= rub);
+//   * the picks are certified in parallel: every wave ranks its own top among the sixteen (one ballot), the up to four
+//     best check themselves against the better ones (lanes = waves), write their verdict, and after a second barrier
+//     every wave reads the verdicts: n = 1 + the number of leading certified ranks.
+template <int T, int MODE, int BH>
+__device__ __forceinline__ void
+fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
+                     unsigned long long* pkey, float4* pxyz, float4* bxyz, float4* sel, int* okf,
+                     long long* __restrict__ irow, float* __restrict__ orow, const int tid, const int lane, const int wave,
+                     unsigned long long key, const float (&blo)[3], const float (&bhi)[3], float sx, float sy, float sz)
+{
+    constexpr int NW = T / 64, BS = 64 * BH;
+    constexpr unsigned long long LOW = (1ull << NW) - 1ull;
+    unsigned sec = (unsigned)(key >> 32);                        // runner-up VALUE of the bucket, or any upper bound of it
+    int n = 1;
+    float s[4][3];                                               // the round's samples (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i][0] = sx; s[i][1] = sy; s[i][2] = sz; }
+    if (tid < 8) okf[tid] = 0;
+    unsigned long long cand = 0ull;                              // the wave's best point, its bucket, its rub
+    int cand_j = wave;
+    unsigned c2 = 0u;
+    bool cached = false;
+    __syncthreads();
+#ifdef PCP_FPS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, sT = 0, sS = 0, sP = 0, sB1 = 0, sK = 0, sB2 = 0, nR = 0, nPass = 0, nAct = 0, nHit = 0, nIdle = 0;
+    const int kd0 = kd;
+#endif
+    for (int round = 0;; ++round) {
+        const int par = round & 1;
+        STAMP(t0);
+        // ---- bucket tests by the owning lanes: which samples could change the bucket, and do they reach its arg-max row
+        const float4 ps = bxyz[lane * NW + wave];
+        const float cmax = __uint_as_float((unsigned)(key >> 32));
+        unsigned affb = 0u;
+        bool hit = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < n) {                                         // wave-uniform
+                const float qx = __builtin_amdgcn_fmed3f(s[i][0], blo[0], bhi[0]);   // clamp(sample, box)
+                const float qy = __builtin_amdgcn_fmed3f(s[i][1], blo[1], bhi[1]);
+                const float qz = __builtin_amdgcn_fmed3f(s[i][2], blo[2], bhi[2]);
+                const bool a = dist2<MODE>(s[i][0], s[i][1], s[i][2], qx, qy, qz) < cmax;
+                affb |= a ? (1u << i) : 0u;
+                hit = hit || (a && dist2<MODE>(s[i][0], s[i][1], s[i][2], ps.x, ps.y, ps.z) < cmax);
+            }
+        }
+        const unsigned long long amask = __ballot(affb != 0u);
+        const unsigned long long hmask = __ballot(hit);
+        // the wave's partial changes only if a bucket that is reduced this round could be its top or its runner-up
+        const bool rebuild = !cached || __ballot(hit && (unsigned)(key >> 32) >= c2) != 0ull;
+        if (rebuild) { cand = 0ull; cand_j = wave; c2 = 0u; }
+        auto idle_top2 = [&]() {                                 // over the buckets that keep their key this round
+            const unsigned long long kb = hit ? 0ull : key;
+            const unsigned h = (unsigned)(kb >> 32), lo = (unsigned)kb;
+            unsigned a1 = h, a2 = hit ? 0u : sec;
+            wave_top2_u32(a1, a2);
+            unsigned long long hm = __ballot(h == a1);
+            int src;
+            unsigned l;
+            if (__popcll(hm) == 1) {
+                src = __ffsll((long long)hm) - 1;
+                l = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+            } else {
+                l = wave_umax_u32(h == a1 ? lo : 0u);
+                hm = __ballot(h == a1 && lo == l);
+                src = __ffsll((long long)hm) - 1;
+            }
+            cand = ((unsigned long long)a1 << 32) | l;
+            cand_j = src * NW + wave;
+            c2 = a2;
+        };
+        auto merge = [&](unsigned long long wk, unsigned ws, int j) {     // all wave-uniform
+            if (wk > cand) { c2 = max(c2, max((unsigned)(cand >> 32), ws)); cand = wk; cand_j = j; }
+            else c2 = max(c2, (unsigned)(wk >> 32));
+        };
+        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], bool first) {
+            constexpr int G = decltype(GC)::value;
+            constexpr bool FULL = decltype(FC)::value;           // every bucket of the pass has all its rows
+            int r0[G];
+            float4 pt[G];
+            float mm[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {                        // BH > 1: BH consecutive slots are the parts of one bucket
+                r0[u] = (ol[u] * NW + wave) * BS + (u % BH) * 64;
+                if (FULL) {                                      // scalar base + lane: no per-lane address math
+                    pt[u] = (S + r0[u])[lane];
+                    mm[u] = (D + r0[u])[lane];
+                } else {
+                    const int r = min(r0[u] + lane, M - 1);
+                    pt[u] = S[r];
+                    mm[u] = D[r];
+                }
+            }
+            if (first && rebuild) {                              // VALU work under the memory latency
+                idle_top2();
+#ifdef PCP_FPS_STAMPS
+                nIdle += 1;
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < G; ++u)                          // keep hipcc from sinking a load into the update branch
+                asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
+            unsigned long long bk[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int r = r0[u] + lane;
+                const unsigned ab = (unsigned)__builtin_amdgcn_readlane((int)affb, ol[u]);   // the samples this bucket needs
+                float m = mm[u];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((ab >> i) & 1u)                          // wave-uniform; fminf keeps m when d is NaN, like `d < m`
+                        m = fminf(m, dist2<MODE>(s[i][0], s[i][1], s[i][2], pt[u].x, pt[u].y, pt[u].z));
+                }
+                const bool live = FULL || r < M;
+                if (live && m < mm[u]) D[r] = m;
+                bk[u] = live ? make_key(m, (unsigned)__float_as_int(pt[u].w)) : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < G; q += BH) {
+                if (q > 0 && ol[q] == ol[0]) continue;           // a left-over slot repeats slot 0
+                if (!((hmask >> ol[q]) & 1ull)) continue;        // the arg-max row kept its value: so did the key
+#ifdef PCP_FPS_STAMPS
+                nHit += 1;
+#endif
+                unsigned long long pk[BH], wk[BH];
+                unsigned zr[BH], ws[BH];
+                int src[BH];
+#pragma unroll
+                for (int h = 0; h < BH; ++h) { pk[h] = bk[q + h]; zr[h] = 0u; }
+                wave_argmax2_key_x<BH>(pk, zr, wk, ws, src);
+                const int j = ol[q] * NW + wave;
+                int w = 0;                                       // scalar: the part that holds the bucket's top
+                unsigned long long wb = wk[0];
+                unsigned wsb = ws[0];
+#pragma unroll
+                for (int h = 1; h < BH; ++h) {
+                    if (wk[h] > wb) { wsb = max(wsb, max((unsigned)(wb >> 32), ws[h])); wb = wk[h]; w = h; }
+                    else wsb = max(wsb, (unsigned)(wk[h] >> 32));
+                }
+#pragma unroll
+                for (int h = 0; h < BH; ++h)
+                    if (w == h && lane == src[h]) bxyz[j] = pt[q + h];
+                if (lane == ol[q]) { key = wb; sec = wsb; }
+                if (rebuild) merge(wb, wsb, j);
+            }
+        };
+        bool first = true;
+        STAMP(t1);
+        __builtin_amdgcn_s_setprio(3);
+        {
+            unsigned long long m = amask;
+#ifdef PCP_FPS_STAMPS
+            nAct += __popcll(m);
+#endif
+            while (m) {                                          // wave-uniform
+#ifdef PCP_FPS_STAMPS
+                nPass += 1;
+#endif
+                int ol[4], nb = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u += BH) {                // 4 / BH buckets per pass, BH slots each
+                    if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; nb = u + BH; }
+                    else ol[u] = ol[0];
+#pragma unroll
+                    for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
+                }
+                using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                using I4 = std::integral_constant<int, 4>;
+                // only the cloud's last bucket can be short of rows; it belongs to lane (NB-1)/NW
+                const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || !((amask >> (((NB - 1) / NW) & 63)) & 1ull);
+                if (full) {
+                    if constexpr (BH == 1) {
+                        if (nb == 1) run_pass(I1{}, std::true_type{}, ol, first);
+                        else if (nb == 2) run_pass(I2{}, std::true_type{}, ol, first);
+                        else run_pass(I4{}, std::true_type{}, ol, first);
+                    } else if constexpr (BH == 2) {
+                        if (nb == 2) run_pass(I2{}, std::true_type{}, ol, first);
+                        else run_pass(I4{}, std::true_type{}, ol, first);
+                    } else {
+                        run_pass(I4{}, std::true_type{}, ol, first);
+                    }
+                } else {
+                    run_pass(I4{}, std::false_type{}, ol, first);
+                }
+                first = false;
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (first && rebuild) idle_top2();                       // nothing to stream, but no partial yet
+        cached = true;
+        STAMP(t2);
+        // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
+        if (rebuild && lane == 0) {
+            const float4 bx = bxyz[cand_j];
+            pkey[wave] = cand;
+            pxyz[wave] = make_float4(bx.x, bx.y, bx.z, __uint_as_float(c2));
+        }
+        STAMP(t3);
+        // workgroup barrier WITHOUT draining global stores (see the one-pick loop)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        STAMP(t4);
+        // ---- the picks: every wave ranks its own top among the NW partials (lane w = wave w)
+        const unsigned long long kk = pkey[lane & (NW - 1)];
+        const float4 cc = pxyz[lane & (NW - 1)];
+        const unsigned long long gt = __ballot(kk > cand) & LOW;                 // the waves whose top beats this one's
+        const int rank = __popcll(gt);
+        if (wave == 0 && lane < 4) okf[(par ^ 1) * 4 + lane] = 0;                // next round's verdicts start at "no"
+        if (cand != 0ull && rank < 4) {                                          // wave-uniform
+            const unsigned hi_own = (unsigned)(cand >> 32);
+            const float ox = rl(cc.x, wave), oy = rl(cc.y, wave), oz = rl(cc.z, wave);
+            bool ok = true;
+            if (rank > 0) {
+                const unsigned long long tie = __ballot((unsigned)(kk >> 32) == hi_own) & LOW & ~(1ull << wave);
+                const float d = dist2<MODE>(cc.x, cc.y, cc.z, ox, oy, oz);       // lane j: the better pick a_j against this one
+                const bool fin = dist2<MODE>(cc.x, cc.y, cc.z, cc.x, cc.y, cc.z) == 0.f;
+                const unsigned long long bad =
+                    __ballot(d < __uint_as_float(hi_own) || !(__float_as_uint(cc.w) < hi_own) || !fin) & gt;
+                ok = tie == 0ull && bad == 0ull && hi_own != 0u;
+            }
+            if (lane == 0) {
+                sel[par * 4 + rank] = make_float4(ox, oy, oz, __int_as_float((int)(~(unsigned)cand)));
+                okf[par * 4 + rank] = ok ? 1 : 0;
+            }
+        }
+        STAMP(t5);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float4 sm = sel[par * 4 + (lane & 3)];
+        const int okv = okf[par * 4 + (lane & 3)];
+        const unsigned okm = (unsigned)(__ballot(okv != 0) & 0xfull);            // bit 0: the arg-max itself, always certain
+        n = min(__ffs((int)~okm) - 1, min(4, kn - kd));                          // leading certified ranks
+        if (cand != 0ull && rank < n && lane == 0) {                             // the picked waves write their pick
+            irow[kd + rank] = (long long)(int)(~(unsigned)cand);
+            if (orow) {
+                orow[3 * (kd + rank)] = rl(cc.x, wave); orow[3 * (kd + rank) + 1] = rl(cc.y, wave); orow[3 * (kd + rank) + 2] = rl(cc.z, wave);
+            }
+        }
+        kd += n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[i][0] = rl(sm.x, i); s[i][1] = rl(sm.y, i); s[i][2] = rl(sm.z, i); }
+#ifdef PCP_FPS_STAMPS
+        { unsigned long long t6; STAMP(t6); sT += t1 - t0; sS += t2 - t1; sP += t3 - t2; sB1 += t4 - t3; sK += t5 - t4; sB2 += t6 - t5; nR += 1; }
+#endif
+        if (kd >= kn) break;
+    }
+#ifdef PCP_FPS_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW - 1))
+        printf("[stamps] wave %d M=%d NB=%d picks=%d rounds=%llu | cycles per round: test=%llu stream=%llu publish=%llu barrier1=%llu picker=%llu barrier2+read=%llu | per round: passes=%.2f buckets=%.2f reduced=%.2f rebuilds=%.2f\n",
+               wave, M, NB, kn - kd0, nR, sT / nR, sS / nR, sP / nR, sB1 / nR, sK / nR, sB2 / nR, (double)nPass / nR, (double)nAct / nR, (double)nHit / nR, (double)nIdle / nR);
+#endif
+}
+
 template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
-    // cell histogram | red | wave partial keys [2][NW] | their xyz [2][NW] | bucket arg-max xyz [T*CPL] | round picks [4] + count
-    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 4 * 16 + 16 + 64;
+    // cell histogram | red | wave partial keys [2][NW] | their xyz [2][NW] | bucket arg-max xyz [T*CPL] | round picks [2][4] + verdicts [2][4]
+    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 8 * 16 + 8 * 4 + 64;
 }
 
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false>
@@ -1079,329 +1351,14 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         irow[k0] = last;
         if (orow) { orow[3 * k0] = sx; orow[3 * k0 + 1] = sy; orow[3 * k0 + 2] = sz; }
     }
-    int kd = k0 + 1;                                            // picks decided (and written) so far
-    if (kd >= kn) return;
-
-    // MULTI-PICK ROUNDS.  One round applies the n <= 4 newest samples to every bucket any of them could change
-    // (one pass over a bucket's rows for all of them), then certifies up to four further picks at once:
-    //   every wave publishes its best point (key, xyz) and `rub`, an upper bound of every OTHER min-distance it owns
-    //   (the second-largest value of the multiset {bucket top, bucket runner-up} over its buckets).  Let a1 > a2 > ...
-    //   be the wave tops in key order, from waves w1, w2, ...  a1 is the next pick, as ever.  a_i is certainly the
-    //   pick after a_(i-1) when for every earlier pick a_j of this round
-    //       rub(w_j) < value(a_i)             nothing else in an earlier winner's wave can overtake a_i,
-    //       !(dist2(a_j, a_i) < value(a_i))   applying a_j leaves a_i's min-distance as it is,
-    //       a_j is finite                     its own min-distance drops to 0 once it is applied,
-    //   and value(a_i) is strictly above every remaining wave top: all other points only lose min-distance, so a_i
-    //   stays the arg-max (ties on a value end the chain, the next round resolves them by index as a first pick).
-    // min() is exact and commutative, so applying a round's samples together leaves the same min-distances as
-    // applying them one by one; a bucket test against the older, larger bucket maximum only streams a superset.
-    // The picks are therefore the sequential ones, in order — with a third of the workgroup rounds on the bench
-    // clouds (tests/model_fps_multipick.py: 350 rounds for 1,023 picks).  One wave certifies the picks between two
-    // barriers instead of all sixteen doing it redundantly: the chain is ~4x longer than a single arg-max and
-    // sixteen copies of it would occupy every SIMD of the CU (and of the workgroup sharing it).
-    float4* sel = bxyz + NBMAX;                                          // [4] the round's picks {x,y,z,bits(idx)}
-    int* nselp = (int*)(sel + 4);                                        // their number
-    unsigned sec[CPL];                                                   // runner-up VALUE of the bucket (an upper bound is enough)
-#pragma unroll
-    for (int s = 0; s < CPL; ++s) sec[s] = (unsigned)(key[s] >> 32);     // unknown yet: as large as the top
-    float4 sm = make_float4(sx, sy, sz, 0.f);                            // lane i < n: sample i of the round (copy of sel[i])
-    int n = 1;
-    if (tid == 0) sel[0] = sm;
-    __syncthreads();
-    unsigned long long cand = 0ull;                                      // the wave's best point, its bucket, its rub
-    int cand_j = wave;
-    unsigned c2 = 0u;
-    bool cached = false;
-#ifdef PCP_FPS_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, sT = 0, sS = 0, sP = 0, sB1 = 0, sK = 0, sB2 = 0, nR = 0, nPass = 0, nAct = 0;
-#endif
-    for (;;) {
-        STAMP(t0);
-        // bucket tests by the owning lanes, against every sample of the round
-        unsigned long long amask[CPL];
-        bool any = false;
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) {
-            const float cmax = __uint_as_float((unsigned)(key[s] >> 32));
-            bool aff = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < n) {                                             // wave-uniform
-                    const float ax = rl(sm.x, i), ay = rl(sm.y, i), az = rl(sm.z, i);
-                    const float qx = __builtin_amdgcn_fmed3f(ax, blo[s][0], bhi[s][0]);   // clamp(sample, box)
-                    const float qy = __builtin_amdgcn_fmed3f(ay, blo[s][1], bhi[s][1]);
-                    const float qz = __builtin_amdgcn_fmed3f(az, blo[s][2], bhi[s][2]);
-                    aff = aff || dist2<MODE>(ax, ay, az, qx, qy, qz) < cmax;
-                }
-            }
-            amask[s] = __ballot(aff);
-            any = any || amask[s] != 0ull;
-        }
-        // The wave's partial (cand, cand_j, c2) is rebuilt whenever one of its buckets changes: the untouched buckets
-        // are reduced while the first loads are in flight, every streamed bucket is merged in as it finishes.
-        const bool rebuild = any || !cached;
-        if (rebuild) { cand = 0ull; cand_j = wave; c2 = 0u; }
-        auto idle_top2 = [&]() {
-            unsigned long long kb = 0ull;
-            unsigned v2 = 0u;
-            int sb = 0;
-#pragma unroll
-            for (int s = 0; s < CPL; ++s) {
-                const bool act = (amask[s] >> lane) & 1ull;
-                if (!act) {
-                    if (key[s] > kb) { v2 = max(v2, max((unsigned)(kb >> 32), sec[s])); kb = key[s]; sb = s; }
-                    else v2 = max(v2, (unsigned)(key[s] >> 32));
-                }
-            }
-            const unsigned h = (unsigned)(kb >> 32), lo = (unsigned)kb;
-            unsigned a1 = h, a2 = v2;
-            wave_top2_u32(a1, a2);
-            unsigned long long hit = __ballot(h == a1);
-            int src;
-            unsigned l;
-            if (__popcll(hit) == 1) {
-                src = __ffsll((long long)hit) - 1;
-                l = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
-            } else {
-                l = wave_umax_u32(h == a1 ? lo : 0u);
-                hit = __ballot(h == a1 && lo == l);
-                src = __ffsll((long long)hit) - 1;
-            }
-            cand = ((unsigned long long)a1 << 32) | l;
-            cand_j = (__builtin_amdgcn_readlane(sb, src) * 64 + src) * NW + wave;
-            c2 = a2;
-        };
-        auto merge = [&](unsigned long long wk, unsigned ws, int j) {     // all wave-uniform
-            if (wk > cand) { c2 = max(c2, max((unsigned)(cand >> 32), ws)); cand = wk; cand_j = j; }
-            else c2 = max(c2, (unsigned)(wk >> 32));
-        };
-        // The wave streams its own active buckets, up to four in flight; the pass body is
-        // instantiated for 1, 2 and 4 buckets so a short pass does not pay for dead slots.
-        auto run_pass = [&](auto GC, auto FC, const int (&ol)[4], unsigned long long& key_s, unsigned& sec_s, int s_idx,
-                            bool first) {
-            constexpr int G = decltype(GC)::value;
-            constexpr bool FULL = decltype(FC)::value;          // every bucket of the pass has all its rows
-            int r0[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u)                         // BH > 1: BH consecutive slots are the parts of one bucket
-                r0[u] = ((s_idx * 64 + ol[u]) * NW + wave) * BS + (u % BH) * 64;
-            unsigned long long bk[G];
-            unsigned bs[G];                                     // MULTI: the lane's runner-up value over the chunks
-            float4 bp[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) bs[u] = 0u;
-            const int nchunks = MULTI ? chunks : 1;
-            for (int c = 0; c < nchunks; ++c) {
-                float4 pt[G];
-                float mm[G];
-#pragma unroll
-                for (int u = 0; u < G; ++u) {                   // unconditional loads: all in flight together
-                    if (FULL) {                                 // scalar base + lane: no per-lane address math
-                        pt[u] = (S + (r0[u] + c * 64))[lane];
-                        mm[u] = (D + (r0[u] + c * 64))[lane];
-                    } else {
-                        const int r = min(r0[u] + c * 64 + lane, M - 1);
-                        pt[u] = S[r];
-                        mm[u] = D[r];
-                    }
-                }
-                // the round's samples come back from LDS as broadcast reads (every lane the same address): they arrive
-                // long before the rows do and are plain VGPR operands of the distance code, dead again before the arg-max
-                if (first && c == 0) idle_top2();               // VALU work under the memory latency
-                float sa[4][3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* sf = (const float*)(sel + (i < n ? i : 0));
-                    sa[i][0] = sf[0]; sa[i][1] = sf[1]; sa[i][2] = sf[2];
-                }
-#pragma unroll
-                for (int u = 0; u < G; ++u)                     // keep hipcc from sinking a load into the update branch
-                    asm volatile("" : "+v"(mm[u]), "+v"(pt[u].w));
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int r = r0[u] + c * 64 + lane;
-                    float m = mm[u];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (i < n)                              // fminf keeps m when d is NaN, like a `d < m` update
-                            m = fminf(m, dist2<MODE>(sa[i][0], sa[i][1], sa[i][2], pt[u].x, pt[u].y, pt[u].z));
-                    }
-                    const bool live = FULL || r < M;
-                    if (live && m < mm[u]) D[r] = m;
-                    const unsigned long long kk = live ? make_key(m, (unsigned)__float_as_int(pt[u].w)) : 0ull;
-                    if (!MULTI || c == 0) { bk[u] = kk; bp[u] = pt[u]; }
-                    else if (kk > bk[u]) { bs[u] = max(bs[u], (unsigned)(bk[u] >> 32)); bk[u] = kk; bp[u] = pt[u]; }
-                    else bs[u] = max(bs[u], (unsigned)(kk >> 32));
-                }
-            }
-            unsigned long long wk[G];
-            unsigned ws[G];
-            int src[G];
-            if constexpr (G == 4) {                             // two chains of two: fewer live registers than four at once
-                unsigned long long bk2[2], wk2[2];
-                unsigned bs2[2], ws2[2];
-                int src2[2];
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    bk2[0] = bk[g]; bk2[1] = bk[g + 1]; bs2[0] = bs[g]; bs2[1] = bs[g + 1];
-                    wave_argmax2_key_x<2>(bk2, bs2, wk2, ws2, src2);
-                    wk[g] = wk2[0]; wk[g + 1] = wk2[1]; ws[g] = ws2[0]; ws[g + 1] = ws2[1]; src[g] = src2[0]; src[g + 1] = src2[1];
-                }
-            } else {
-                wave_argmax2_key_x<G>(bk, bs, wk, ws, src);
-            }
-            if constexpr (BH > 1 && G < BH) {
-                // never called: a split bucket occupies BH slots
-            } else if constexpr (BH > 1) {
-#pragma unroll
-                for (int q = 0; q < G; q += BH) {               // the bucket's top / runner-up over its parts
-                    const int j = (s_idx * 64 + ol[q]) * NW + wave;
-                    int w = q;                                  // scalar
-                    unsigned long long wb = wk[q];
-                    unsigned wsb = ws[q];
-#pragma unroll
-                    for (int h = 1; h < BH; ++h) {
-                        if (wk[q + h] > wb) { wsb = max(wsb, max((unsigned)(wb >> 32), ws[q + h])); wb = wk[q + h]; w = q + h; }
-                        else wsb = max(wsb, (unsigned)(wk[q + h] >> 32));
-                    }
-#pragma unroll
-                    for (int h = 0; h < BH; ++h)
-                        if (w == q + h && lane == src[q + h]) bxyz[j] = bp[q + h];
-                    if (lane == ol[q]) { key_s = wb; sec_s = wsb; }
-                    merge(wb, wsb, j);
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int j = (s_idx * 64 + ol[u]) * NW + wave;
-                    if (lane == src[u]) bxyz[j] = bp[u];
-                    if (lane == ol[u]) { key_s = wk[u]; sec_s = ws[u]; }
-                    if (u == 0 || ol[u] != ol[0]) merge(wk[u], ws[u], j);      // a left-over slot repeats slot 0
-                }
-            }
-        };
-        bool first = true;
-        STAMP(t1);
-        __builtin_amdgcn_s_setprio(3);                          // the streaming phase is the round's critical path
-#pragma unroll
-        for (int s = 0; s < CPL; ++s) {
-            unsigned long long m = amask[s];
-#ifdef PCP_FPS_STAMPS
-            nAct += __popcll(m);
-#endif
-            while (m) {                                         // wave-uniform
-#ifdef PCP_FPS_STAMPS
-                nPass += 1;
-#endif
-                int ol[4], nb = 0;
-                if constexpr (BH > 1) {                         // 4 / BH buckets per pass, BH slots each
-#pragma unroll
-                    for (int u = 0; u < 4; u += BH) {
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; nb = u + BH; }
-                        else ol[u] = ol[0];
-#pragma unroll
-                        for (int h = 1; h < BH; ++h) ol[u + h] = ol[u];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {               // a fourth slot left over repeats slot 0: harmless
-                        if (m) { ol[u] = __ffsll((long long)m) - 1; m &= m - 1; nb = u + 1; }
-                        else ol[u] = ol[0];
-                    }
-                }
-                using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-                using I4 = std::integral_constant<int, 4>;
-                // only the cloud's last bucket can be short of rows; it belongs to lane (NB-1)/NW % 64
-                const bool full = (M % BS == 0) || (((NB - 1) % NW) != wave) || (((NB - 1) / NW) >> 6) != s ||
-                                  !((amask[s] >> (((NB - 1) / NW) & 63)) & 1ull);
-                if (full) {
-                    if (nb == 1) run_pass(I1{}, std::true_type{}, ol, key[s], sec[s], s, first);
-                    else if (nb == 2) run_pass(I2{}, std::true_type{}, ol, key[s], sec[s], s, first);
-                    else run_pass(I4{}, std::true_type{}, ol, key[s], sec[s], s, first);
-                } else {
-                    run_pass(I4{}, std::false_type{}, ol, key[s], sec[s], s, first);
-                }
-                first = false;
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (first && !cached) idle_top2();                      // nothing to stream and no partial yet
-        cached = true;
-        STAMP(t2);
-        // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
-        if (lane == 0) {
-            const float4 bx = bxyz[cand_j];
-            pkey[wave] = cand;
-            pxyz[wave] = make_float4(bx.x, bx.y, bx.z, __uint_as_float(c2));
-        }
-        // Workgroup barrier WITHOUT draining global stores: only LDS traffic (the partials) has to be
-        // visible to the other waves.  The min_d stores of this round are re-read by this wave alone
-        // (a bucket is streamed by its owning wave only), and same-wave accesses stay ordered, so
-        // waiting for their acknowledgements — which __syncthreads() does — is wasted serial time.
-        STAMP(t3);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        STAMP(t4);
-        if (wave == 0) {                                        // the picker
-            constexpr unsigned long long LOW = (1ull << NW) - 1ull;
-            const unsigned long long kk = pkey[lane & (NW - 1)];
-            const float4 cc = pxyz[lane & (NW - 1)];
-            int src[4] = {0, 0, 0, 0};
-            (void)lowlanes_argmax_key<NW>(kk, &src[0]);
-            int np = 1;
-            const int nmax = min(4, kn - kd);
-            const unsigned rubv = __float_as_uint(cc.w);
-            unsigned v = (unsigned)(kk >> 32);
-            unsigned long long chosen = 1ull << src[0];
-            const unsigned long long selfok = __ballot(dist2<MODE>(cc.x, cc.y, cc.z, cc.x, cc.y, cc.z) == 0.f);
-#pragma unroll
-            for (int t = 1; t < 4; ++t) {
-                if (np != t || t >= nmax) break;                // all wave-uniform
-                if (!((selfok >> src[t - 1]) & 1ull)) break;    // a non-finite pick keeps its min-distance: it is next again
-                v = lane == src[t - 1] ? 0u : v;
-                unsigned m = v;
-                m = max(m, dpp_u32<0xB1>(m));
-                m = max(m, dpp_u32<0x4E>(m));
-                if (NW > 4) m = max(m, dpp_u32<0x141>(m));
-                if (NW > 8) m = max(m, dpp_u32<0x140>(m));
-                m = (unsigned)__builtin_amdgcn_readlane((int)m, 0);
-                if (m == 0u) break;
-                const unsigned long long hit = __ballot(v == m) & LOW;
-                if (__popcll(hit) != 1) break;                  // a tie on the value: index order decides, next round
-                const int s = __ffsll((long long)hit) - 1;
-                const float d = dist2<MODE>(cc.x, cc.y, cc.z, rl(cc.x, s), rl(cc.y, s), rl(cc.z, s));
-                const unsigned long long bad = __ballot(d < __uint_as_float(m) || !(rubv < m)) & chosen;
-                if (bad) break;
-                chosen |= 1ull << s;
-                src[t] = s;
-                np = t + 1;
-            }
-            int pos = -1;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (t < np && lane == src[t]) pos = t;
-            if (pos >= 0) {
-                const int id = kk ? (int)(~(unsigned)kk) : 0;
-                sel[pos] = make_float4(cc.x, cc.y, cc.z, __int_as_float(id));
-                irow[kd + pos] = id;
-                if (orow) { orow[3 * (kd + pos)] = cc.x; orow[3 * (kd + pos) + 1] = cc.y; orow[3 * (kd + pos) + 2] = cc.z; }
-            }
-            if (lane == 0) *nselp = np;
-        }
-        STAMP(t5);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        sm = sel[lane & 3];
-        n = __builtin_amdgcn_readfirstlane(*nselp);
-        kd += n;
-#ifdef PCP_FPS_STAMPS
-        { unsigned long long t6; STAMP(t6); sT += t1 - t0; sS += t2 - t1; sP += t3 - t2; sB1 += t4 - t3; sK += t5 - t4; sB2 += t6 - t5; nR += 1; }
-#endif
-        if (kd >= kn) break;
+    if (k0 + 1 >= kn) return;
+    if constexpr (MP) {
+        static_assert(!MULTI && CPL == 1, "multi-pick rounds are a variant of the wide shape");
+        float4* sel = bxyz + NBMAX;                                      // [2][4] a round's picks {x,y,z,bits(idx)}
+        int* okf = (int*)(sel + 8);                                      // [2][4] their verdicts
+        fps_multipick_rounds<T, MODE, BH>(k0 + 1, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, irow, orow, tid, lane, wave,
+                                          key[0], blo[0], bhi[0], sx, sy, sz);
     }
-#ifdef PCP_FPS_STAMPS
-    if (b == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW - 1))
-        printf("[stamps] wave %d M=%d NB=%d picks=%d rounds=%llu | cycles per round: test=%llu stream=%llu publish=%llu barrier1=%llu picker=%llu barrier2+read=%llu | passes/round=%.2f buckets/round=%.2f\n",
-               wave, M, NB, kn - 1 - k0, nR, sT / nR, sS / nR, sP / nR, sB1 / nR, sK / nR, sB2 / nR, (double)nPass / nR, (double)nAct / nR);
-#endif
 }
 
 // "wide" shape (single-chunk buckets): two workgroups of 1024 (four of 512) per CU, so every frame of a
@@ -1492,8 +1449,11 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
                  int, int*);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
-    else if (c.mp > 0 || (c.mp == 0 && c.B <= PCP_FPS_MP_MAX_B)) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
-    else kern = fps_bucket_wide<T, CPL, MODE, BH>;
+    else {
+        kern = fps_bucket_wide<T, CPL, MODE, BH>;
+        if constexpr (CPL == 1)
+            if (c.mp > 0 || (c.mp == 0 && c.B <= PCP_FPS_MP_MAX_B)) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
+    }
     // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
     // (lazy: 0 = by batch size, 1 = always, -1 = never)
     const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;

@@ -1390,6 +1390,20 @@ fps_bucket_wide_mp(const float* __restrict__ xyz, const long long* __restrict__ 
                                                    m_cap, overflow);
 }
 
+// The same kernel held to 64 VGPRs / 80 SGPRs (scalar registers spill to VGPR lanes) so that TWO workgroups fit a CU:
+// for batches of more than one cloud per CU (the 300-frame episode).  Slightly slower per workgroup, but every cloud is
+// resident at once — 2.90 instead of 3.84 ms per 300 frames, and ahead of the one-pick kernel's 3.10.
+template <int T, int CPL, int MODE, int BH = 1>
+__global__ void __launch_bounds__(T, 8) __attribute__((amdgpu_num_sgpr(80), amdgpu_num_vgpr(64)))
+fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
+                    long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                    float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
+                    int* __restrict__ overflow)
+{
+    fps_bucket_body<T, CPL, false, MODE, BH, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
+                                                   m_cap, overflow);
+}
+
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
 template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
@@ -1405,7 +1419,7 @@ fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ off
 // ---- host entry points -------------------------------------------------------------------------
 static int fps_pick_algo(int algo, int64_t max_pts)
 {
-    if (algo >= 2) return 2;                 // 3 / 4: bucket kernels with the deferred rounds forced on / off; 5 / 6: multi-pick rounds on / off
+    if (algo >= 2) return 2;                 // 3 / 4: deferred rounds forced on / off; 5 / 6: multi-pick rounds on / off; 7 / 8: multi-pick + deferred off / on
     if (algo == 1) return 1;
     return max_pts >= 2048 ? 2 : 1;
 }
@@ -1440,7 +1454,7 @@ struct FpsCall {                 // everything a launch needs besides its shape
 };
 
 #ifndef PCP_FPS_MP_MAX_B
-#define PCP_FPS_MP_MAX_B 0       // multi-pick rounds for batches of at most this many clouds (0: only when asked for, algo 5)
+#define PCP_FPS_MP_MAX_B 256     // multi-pick rounds for batches of at most this many clouds (one workgroup per CU)
 #endif
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
@@ -1451,12 +1465,20 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
     else {
         kern = fps_bucket_wide<T, CPL, MODE, BH>;
-        if constexpr (CPL == 1)
-            if (c.mp > 0 || (c.mp == 0 && c.B <= PCP_FPS_MP_MAX_B)) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
+        if constexpr (CPL == 1) {
+            if (c.mp >= 0) {
+                if (c.B <= PCP_FPS_MP_MAX_B) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;       // one workgroup per CU
+                else if (BH <= 2) kern = fps_bucket_wide_mp2<T, CPL, MODE, (BH <= 2 ? BH : 1)>;  // two (the quartered-bucket shape spills at 64 VGPRs)
+                else if (c.mp > 0) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
+            }
+        }
     }
     // deferred updates pay once the batch keeps the fabric busy (measured: from about one cloud per CU)
     // (lazy: 0 = by batch size, 1 = always, -1 = never)
-    const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= PCP_FPS_LAZY_MIN_B)) ? PCP_FPS_LAZY_ROUNDS : 0;
+    // (with multi-pick rounds after them only once two workgroups share a CU: measured 1.81 vs 1.90 ms at 192 clouds,
+    //  2.14 vs 2.17 at 256, 3.02 vs 2.91 at 300 without / with the deferred rounds)
+    const int lazy_min_b = c.mp >= 0 ? PCP_FPS_MP_MAX_B + 1 : PCP_FPS_LAZY_MIN_B;
+    const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= lazy_min_b)) ? PCP_FPS_LAZY_ROUNDS : 0;
     if (lds > 48 * 1024)         // the only process-wide state the library touches: a per-kernel attribute, same value every time
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(c.B), dim3(T), lds, c.st, c.xyz, c.offsets, c.K, c.idx, c.out_xyz, c.pts4, c.md,
@@ -1509,7 +1531,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
                             void* ws, size_t ws_bytes, hipStream_t st)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
-        algo < 0 || algo > 6)
+        algo < 0 || algo > 8)
         return PCP_ERR_INVALID_ARG;
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
@@ -1522,8 +1544,8 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.pts4 = (float4*)ws;
     c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
     c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
-    c.lazy = algo == 3 ? 1 : (algo == 4 ? -1 : 0);
-    c.mp = algo == 5 ? 1 : (algo == 6 ? -1 : 0);
+    c.lazy = (algo == 3 || algo == 8) ? 1 : ((algo == 4 || algo == 7) ? -1 : 0);
+    c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 6 ? -1 : 0);
     c.st = st;
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);

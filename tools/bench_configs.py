@@ -38,7 +38,7 @@ def config3(B):
     def f3(): st["s"], st["soff"] = ops.statistical_outlier_removal(st["v"]["xyz64"], st["v"]["rgb32"], st["voff"], 20, 2.0, st["cell"], cap_pts=V, max_extent=ext)
     f3(); S = int(st["soff"][-1].item())
     mx = int((st["soff"][1:] - st["soff"][:-1]).max().item())
-    plan = ops.Fps(B, S, mx, K, depth.device)
+    plan = ops.Fps(B, S, mx, K, depth.device, algo=int(os.environ.get("PCP_FPS_ALGO", "0")))
     def f4():
         st["fx"], st["fi"] = plan.run(st["s"]["xyz32"][:S], st["soff"])
         st["col"] = ops.gather_rgb(st["s"]["rgb32"][:S], st["soff"], st["fi"])
@@ -63,7 +63,7 @@ def config5(F):
     st = {}
     def f1(): st["o"], st["foff"], _ = s1.run(depth, rgb, cams)
     f1(); tot_pts = int(st["foff"][-1].item()); mx = int((st["foff"][1:] - st["foff"][:-1]).max().item())
-    plan = ops.Fps(F, tot_pts, mx, K, depth.device)
+    plan = ops.Fps(F, tot_pts, mx, K, depth.device, algo=int(os.environ.get("PCP_FPS_ALGO", "0")))
     def f2():
         st["fx"], st["fi"] = plan.run(st["o"]["xyz32"][:tot_pts], st["foff"])
         st["col"] = ops.gather_rgb(st["o"]["rgb32"][:tot_pts], st["foff"], st["fi"])

@@ -344,6 +344,9 @@ __device__ __forceinline__ float rl(float v, int lane)
 //             keys, one LDS partial per wave, ONE workgroup barrier, and every wave reduces the
 //             NW partials to the next sample (xyz included, so nothing global is on the
 //             critical path).
+// LDS slot of bucket j's arg-max point: wave-major (bucket j belongs to wave j % NW, its (j / NW)-th), so that the owning
+// lanes of one wave read consecutive 16-byte entries — the bucket-major layout put all 64 of them on the same four banks
+#define PCP_BX(j, NW, PER_WAVE) (((j) % (NW)) * (PER_WAVE) + (j) / (NW))
 #define PCP_FPS_RED 128          // floats of LDS scratch: bounding-box partials (6 per wave, <= 16 waves), scan scratch
 #define PCP_FPS_CELL_BITS 12
 #define PCP_FPS_NCELL (1 << PCP_FPS_CELL_BITS)
@@ -712,7 +715,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
                         if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
 #pragma unroll
                     for (int h = 0; h < BH; ++h)
-                        if (w == q + h && lane == src[q + h]) bxyz[j] = pt[q + h];
+                        if (w == q + h && lane == src[q + h]) bxyz[PCP_BX(j, NW, 64)] = pt[q + h];
                     if (lane == ol[q]) { key = wb; pend = 0u; }
                     if (wb > cand) { cand = wb; cand_j = j; }
                 }
@@ -720,7 +723,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const int j = ol[u] * NW + wave;
-                    if (lane == src[u]) bxyz[j] = pt[u];
+                    if (lane == src[u]) bxyz[PCP_BX(j, NW, 64)] = pt[u];
                     if (lane == ol[u]) { key = wk[u]; pend = 0u; }
                     if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
                 }
@@ -765,7 +768,7 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
         wmax = cand;
         wmax_j = cand_j;
         if (draining) break;                                    // every bucket clean, each wave's top exact: no pick needed
-        if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
+        if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[PCP_BX(cand_j, NW, 64)]; }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // see the eager loop
         {
             const unsigned long long kk = pkey[par * NW + (lane & (NW - 1))];
@@ -840,7 +843,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
         const int par = round & 1;
         STAMP(t0);
         // ---- bucket tests by the owning lanes: which samples could change the bucket, and do they reach its arg-max row
-        const float4 ps = bxyz[lane * NW + wave];
+        const float4 ps = bxyz[wave * 64 + lane];
         const float cmax = __uint_as_float((unsigned)(key >> 32));
         unsigned affb = 0u;
         bool hit = false;
@@ -950,7 +953,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
                 }
 #pragma unroll
                 for (int h = 0; h < BH; ++h)
-                    if (w == h && lane == src[h]) bxyz[j] = pt[q + h];
+                    if (w == h && lane == src[h]) bxyz[PCP_BX(j, NW, 64)] = pt[q + h];
                 if (lane == ol[q]) { key = wb; sec = wsb; }
                 if (rebuild) merge(wb, wsb, j);
             }
@@ -1002,7 +1005,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
         STAMP(t2);
         // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
         if (rebuild && lane == 0) {
-            const float4 bx = bxyz[cand_j];
+            const float4 bx = bxyz[PCP_BX(cand_j, NW, 64)];
             pkey[wave] = cand;
             pxyz[wave] = make_float4(bx.x, bx.y, bx.z, __uint_as_float(c2));
         }
@@ -1161,7 +1164,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
 
     // every owned slot's arg-max point starts as the first sample: round 0 then "hits" every bucket (distance 0)
 #pragma unroll
-    for (int s = 0; s < CPL; ++s) bxyz[(s * 64 + lane) * NW + wave] = make_float4(sx, sy, sz, 0.f);
+    for (int s = 0; s < CPL; ++s) bxyz[PCP_BX((s * 64 + lane) * NW + wave, NW, (NBMAX / NW))] = make_float4(sx, sy, sz, 0.f);
 
     // ---- rounds -------------------------------------------------------------------------------------
     int k0 = 0;
@@ -1272,7 +1275,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
                             if (wk[q + h] > wb) { wb = wk[q + h]; w = q + h; }
     #pragma unroll
                         for (int h = 0; h < BH; ++h)
-                            if (w == q + h && lane == src[q + h]) bxyz[j] = bp[q + h];
+                            if (w == q + h && lane == src[q + h]) bxyz[PCP_BX(j, NW, (NBMAX / NW))] = bp[q + h];
                         if (lane == ol[q]) key_s = wb;
                         if (wb > cand) { cand = wb; cand_j = j; }
                     }
@@ -1280,7 +1283,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     #pragma unroll
                     for (int u = 0; u < G; ++u) {
                         const int j = (s_idx * 64 + ol[u]) * NW + wave;
-                        if (lane == src[u]) bxyz[j] = bp[u];
+                        if (lane == src[u]) bxyz[PCP_BX(j, NW, (NBMAX / NW))] = bp[u];
                         if (lane == ol[u]) key_s = wk[u];
                         if (wk[u] > cand) { cand = wk[u]; cand_j = j; }      // scalar
                     }
@@ -1328,7 +1331,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
             wmax = cand;                                            // = arg-max over all the wave's buckets again
             wmax_j = cand_j;
             // only this wave ever writes bxyz[cand_j], so the copy cannot race with another wave's update
-            if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[cand_j]; }
+            if (lane == 0) { pkey[par * NW + wave] = cand; pxyz[par * NW + wave] = bxyz[PCP_BX(cand_j, NW, (NBMAX / NW))]; }
             // Workgroup barrier WITHOUT draining global stores: only LDS traffic (the partials) has to be
             // visible to the other waves.  The min_d stores of this round are re-read by this wave alone
             // (a bucket is streamed by its owning wave only), and same-wave accesses stay ordered, so

@@ -1481,7 +1481,10 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     // (with multi-pick rounds after them only once two workgroups share a CU: measured 1.81 vs 1.90 ms at 192 clouds,
     //  2.14 vs 2.17 at 256, 3.02 vs 2.91 at 300 without / with the deferred rounds)
     const int lazy_min_b = c.mp >= 0 ? PCP_FPS_MP_MAX_B + 1 : PCP_FPS_LAZY_MIN_B;
-    const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= lazy_min_b)) ? PCP_FPS_LAZY_ROUNDS : 0;
+    // how many: 256 ahead of the one-pick loop; ahead of the multi-pick rounds, which take over the mid-range rounds better,
+    // 128 up to 400 clouds (300 clouds: 2.83 ms with 96-128, 2.87 with 192, 2.93 with 256; 512 clouds: 3.57 / 3.51 / 3.51)
+    const int lazy_n = (c.mp >= 0 && c.B <= 400) ? PCP_FPS_LAZY_ROUNDS / 2 : PCP_FPS_LAZY_ROUNDS;
+    const int lazy_k = (!MULTI && CPL == 1 && c.lazy >= 0 && (c.lazy > 0 || c.B >= lazy_min_b)) ? lazy_n : 0;
     if (lds > 48 * 1024)         // the only process-wide state the library touches: a per-kernel attribute, same value every time
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(c.B), dim3(T), lds, c.st, c.xyz, c.offsets, c.K, c.idx, c.out_xyz, c.pts4, c.md,

@@ -117,6 +117,12 @@ def test_stage2_restatement_matches_reference(name):
     s1, i1 = cbind.fps(g["fps_in"], 2500, 0)
     np.testing.assert_array_equal(i1, g["idx"])
     np.testing.assert_array_equal(s1, g["out_xyz"])
+    # The recorder scripted these indices with the UN-fused distance form; on the fixture clouds the fused form — what the
+    # drop-in defaults to (use_cuda=True, DP3:47) — picks the same points, so the reference-run fixtures pin crop, cast and
+    # gather under the default mode's indices too (test_gpu_dropin.py runs the mirror in that mode against them).
+    s2, i2 = cbind.fps(g["fps_in"], 2500, 1)
+    np.testing.assert_array_equal(i2, g["idx"])
+    np.testing.assert_array_equal(s2, g["out_xyz"])
 
 
 def test_crop_mask_strict_and_c_equals_numpy():

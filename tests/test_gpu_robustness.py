@@ -53,6 +53,21 @@ def test_fps_cloud_above_max_pts_is_flagged_not_skipped(algo):
     np.testing.assert_array_equal(idx2[1].cpu().numpy(), cbind.fps(clouds[1], K, 0)[1])
 
 
+def test_one_shot_fps_wrapper_raises_on_overflow():
+    """ops.fps_batched() builds a throw-away plan, so nobody could read its overflow flag — it now
+    reads it itself and raises instead of handing back -1 / zero rows (an understated max_pts, offsets past xyz)."""
+    rng = np.random.default_rng(63)
+    sizes = [5000, 70000]
+    pts = np.concatenate([rng.uniform(-0.5, 0.5, (m, 3)).astype(np.float32) for m in sizes])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    with pytest.raises(_ffi.PcpError):
+        ops.fps_batched(dev(pts), dev(off), 32, algo=2, max_pts=6000)
+    with pytest.raises(_ffi.PcpError):
+        ops.fps_batched(dev(pts), dev(np.array([0, 5000, 90000], np.int64)), 32)
+    xyz, idx = ops.fps_batched(dev(pts), dev(off), 32, max_pts=70000)             # an honest bound: no error
+    np.testing.assert_array_equal(idx[1].cpu().numpy(), cbind.fps(pts[5000:], 32, 0)[1])
+
+
 def test_fps_offsets_past_total_pts_are_flagged():
     rng = np.random.default_rng(62)
     pts = rng.uniform(-0.5, 0.5, (9000, 3)).astype(np.float32)

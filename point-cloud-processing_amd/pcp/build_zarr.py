@@ -82,7 +82,7 @@ def _process_traj(data_root, traj, source, K, frame_skip, intr, ext, runner_box)
     return rows, action, state
 
 
-def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=None):
+def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=None, encoded=None):
     """The dataset-level loop of BASELINE configs[3] (S2:34-45 + CHK:47-200) for any episode source.
       lengths[i]  expected frame count of episode i (only used to balance the ranks)
       produce(i)  → None (episode skipped, CHK:67-70 / 127-132) or (rows (n,K,6), action (n,7), state (n,7))
@@ -91,6 +91,9 @@ def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=No
     (shard.write_rows_sharded) — no rank ever holds another rank's rows, nothing is stacked on rank 0, and the only
     data that travels is the rows of the few chunks straddling two ranks plus the (n,7) state / action arrays.
     Rank 0 writes .zarray / action / state / episode_ends.  The store equals a single-process run's byte for byte.
+    encoded: optional ({chunk index: bytes} or a callable returning it, chunk_rows_assumed_counts) — point-cloud chunks
+    this rank encoded ahead of time under the assumption that every episode i yields exactly assumed_counts[i] rows;
+    used only if that turns out to be true for ALL episodes (the common case: no trajectory skipped).
     Returns (total frames, episodes kept)."""
     import time
     from pcp import shard
@@ -124,8 +127,13 @@ def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=No
     if rank == 0:
         zarr_store.create_dp3_layout(out_zarr)
     shard.barrier()
+    pre = None
+    if encoded is not None:
+        get, assumed = encoded
+        if [int(c) for c in assumed] == counts:
+            pre = get() if callable(get) else get
     wrote = shard.write_rows_sharded(os.path.join(out_zarr, "data", "point_cloud"), local_rows, counts, tails.pop(),
-                                     CHUNK_SIZE, "<f4", compressor, threads)
+                                     CHUNK_SIZE, "<f4", compressor, threads, encoded=pre)
     metas = shard.gather_to_root({i: (m[1], m[2]) for i, m in local_meta.items() if m is not None})
     if metas is not None:
         merged = {}
@@ -137,6 +145,7 @@ def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=No
     shard.barrier()
     if timing is not None:
         timing.update(produce_s=t1 - t0, write_s=time.perf_counter() - t1, chunks_written_here=wrote[0],
+                      chunks_encoded_ahead=0 if pre is None else len(pre),
                       boundary_pieces_sent=wrote[1], episodes_here=len(mine))
     return int(sum(counts)), len(kept)
 

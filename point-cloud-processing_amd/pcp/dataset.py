@@ -57,6 +57,15 @@ def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", thr
     mine = shard.assign_contiguous(source.lengths, world)[rank]        # the same deal assemble() makes
     ddt = np.uint16 if source.depth_mm else np.float32
     ready = {}
+    # Chunks are ENCODED (zlib) in the background while the GPU works on the next episodes, under the assumption that no
+    # episode is skipped — then episode i starts at row sum(lengths[:i]) and a group's rows fill known chunks; assemble()
+    # uses them only if the assumption held for every episode of every rank, and encodes the rest (group seams) itself.
+    from concurrent.futures import ThreadPoolExecutor
+    from . import zarr_store
+    starts = np.concatenate([[0], np.cumsum(source.lengths)]).astype(np.int64)
+    R = build_zarr.CHUNK_SIZE
+    enc_pool = ThreadPoolExecutor(max_workers=max(1, threads))
+    enc_futs = {}
     # Episodes are loaded a few at a time and streamed through the runner BACK TO BACK (one chunk stream, no drain at
     # episode boundaries: the upload of an episode's first chunk overlaps the kernels of the previous episode's last).
     for g0 in range(0, len(mine), max(1, int(prefetch))):
@@ -79,6 +88,10 @@ def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", thr
             ready[ep] = (rows[at:at + n], counts[at:at + n], state, action)
             at += n
         del loaded
+        if compressor is not None and (np.asarray(counts) > 0).all():
+            g0 = int(starts[group[0]])                            # the group's rows are [g0, g0 + len(rows)) if nobody skips
+            for c in range(-(-g0 // R), (g0 + rows.shape[0]) // R):
+                enc_futs[c] = enc_pool.submit(zarr_store.encode_chunk, rows[c * R - g0:(c + 1) * R - g0], compressor)
 
     def produce(ep):
         rows, counts, state, action = ready.pop(ep)
@@ -91,7 +104,9 @@ def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", thr
 
     timing = {}
     t0 = time.perf_counter()
-    frames, episodes = build_zarr.assemble(source.lengths, produce, out_zarr, compressor, threads, timing)
+    frames, episodes = build_zarr.assemble(source.lengths, produce, out_zarr, compressor, threads, timing,
+                                           encoded=(lambda: {c: f.result() for c, f in enc_futs.items()}, source.lengths))
+    enc_pool.shutdown(wait=True)
     wall = time.perf_counter() - t0 + t["source_s"] + t["runner_s"]
     runner.close()
     st = runner.stats
@@ -100,7 +115,8 @@ def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", thr
                runner_s=t["runner_s"], zarr_write_s=timing.get("write_s", 0.0),
                staging_s=st["stage_s"], h2d_s=st["h2d_ms"] / 1e3, kernels_s=st["kernels_ms"] / 1e3,
                d2h_s=st["d2h_ms"] / 1e3, gpu_wait_s=st["wait_s"], host_rows_s=st["host_rows_s"],
-               chunks_written_here=timing.get("chunks_written_here", 0), boundary_pieces_sent=timing.get("boundary_pieces_sent", 0))
+               chunks_written_here=timing.get("chunks_written_here", 0), boundary_pieces_sent=timing.get("boundary_pieces_sent", 0),
+               chunks_encoded_ahead=timing.get("chunks_encoded_ahead", 0))
     out["frames_per_s_runner_this_rank"] = mine / t["runner_s"] if t["runner_s"] > 0 else 0.0
     out["frames_per_s_wall"] = frames / wall if wall > 0 else 0.0
     return out

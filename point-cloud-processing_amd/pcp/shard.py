@@ -95,7 +95,7 @@ def stack_for_zarr(episodes):
 
 
 def write_rows_sharded(path, local, counts, tail_shape, chunk_rows=100, dtype="<f4", compressor="zlib", threads=8,
-                       group=None):
+                       group=None, encoded=None):
     """Write ONE zarr array of shape (sum(counts),) + tail_shape, chunked (chunk_rows,) + tail_shape (CHK:188), whose
     rows are the concatenation of the episodes' blocks in episode order, from blocks that live on different ranks.
       local  {episode: ndarray (counts[episode],) + tail_shape} — this rank's episodes
@@ -103,6 +103,8 @@ def write_rows_sharded(path, local, counts, tail_shape, chunk_rows=100, dtype="<
     Every rank compresses and writes the chunks that its own rows fill completely (thread pool; zlib releases the
     GIL).  Pieces of chunks shared with another rank go to rank 0, which assembles those few chunks and writes
     .zarray.  The directory must exist on a file system all ranks see (one node, BASELINE configs[3]).
+    encoded: {chunk index: bytes} — chunks of this rank that the caller has ALREADY encoded (same rows, same chunk grid,
+    same compressor: e.g. compressed in the background while the GPU worked on later episodes); they are only written.
     Returns (chunks written here, boundary pieces sent)."""
     from concurrent.futures import ThreadPoolExecutor
     from . import zarr_store
@@ -139,6 +141,9 @@ def write_rows_sharded(path, local, counts, tail_shape, chunk_rows=100, dtype="<
 
     def write_one(item):
         c, parts = item
+        if encoded is not None and c in encoded:
+            zarr_store.write_chunk_bytes(path, (c,) + zeros, encoded[c])
+            return
         if len(parts) == 1 and parts[0][1].shape[0] == R and parts[0][1].dtype == dt:
             blockc = parts[0][1]
         else:

@@ -57,14 +57,23 @@ def write_zarray(path, shape, chunks, dtype, compressor="zlib"):
     return meta, chunks
 
 
-def write_chunk(path, cidx, block, compressor="zlib"):
-    """One chunk file "i.j.k" from a FULL-chunk-shaped C-contiguous block (edge chunks zero-padded by the caller)."""
+def encode_chunk(block, compressor="zlib"):
+    """The bytes of one chunk file from a FULL-chunk-shaped block (edge chunks zero-padded by the caller)."""
     raw = np.ascontiguousarray(block).tobytes()
     comp = _compressor_meta(compressor)
     if comp:
         raw = zlib.compress(raw, comp["level"])                 # releases the GIL: chunks compress in parallel threads
+    return raw
+
+
+def write_chunk_bytes(path, cidx, raw):
     with open(os.path.join(path, ".".join(str(int(i)) for i in cidx)), "wb") as fh:
         fh.write(raw)
+
+
+def write_chunk(path, cidx, block, compressor="zlib"):
+    """One chunk file "i.j.k" from a FULL-chunk-shaped C-contiguous block."""
+    write_chunk_bytes(path, cidx, encode_chunk(block, compressor))
 
 
 def write_array(path, data, chunks, dtype, compressor="zlib", threads=1):

@@ -41,32 +41,38 @@ class EpisodeRunner:
         self.d_depth_m = torch.empty((self.chunk, H, W), dtype=torch.float32, device=self.dev) if self.depth_mm else None
         if self.rgb_on_host:
             self.h_rgb = self.d_rgb = None
-            self.h_xyz = [mk((self.chunk, K, 3), torch.float32) for _ in range(2)]
-            self.h_cpix = [mk((self.chunk, K), torch.int32) for _ in range(2)]
+            self.h_xyz = [mk((self.chunk, K, 3), torch.float32) for _ in range(3)]
+            self.h_cpix = [mk((self.chunk, K), torch.int32) for _ in range(3)]
             self.h_rows = None
         else:
             self.h_rgb = [mk((self.chunk, self.Hc, self.Wc, 3), torch.uint8) for _ in range(2)]
             self.d_rgb = [torch.empty((self.chunk, self.Hc, self.Wc, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
         self.profile = bool(profile)
         self.stats = dict(frames=0, chunks=0, stage_s=0.0, wait_s=0.0, host_rows_s=0.0, h2d_ms=0.0, kernels_ms=0.0, d2h_ms=0.0)
-        self._ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(2)] if self.profile else None
+        self._ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(3)] if self.profile else None
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
         if not self.rgb_on_host:
-            self.h_rows = [mk((self.chunk, K, 6), torch.float32) for _ in range(2)]
-        self.h_off = [mk((self.chunk + 1,), torch.int64) for _ in range(2)]
-        self.h_flags = [mk((2,), torch.int32) for _ in range(2)]      # stage-1 capacity / FPS bounds flags of the chunk
-        self.done = [torch.cuda.Event() for _ in range(2)]
+            self.h_rows = [mk((self.chunk, K, 6), torch.float32) for _ in range(3)]
+        # input buffers exist twice (slot = chunk parity), result buffers and timing events three times (chunk % 3): the
+        # collector may still be reading chunk i-1's results while chunk i+1 is uploaded into chunk i-1's input slot
+        self.h_off = [mk((self.chunk + 1,), torch.int64) for _ in range(3)]
+        self.h_flags = [mk((2,), torch.int32) for _ in range(3)]      # stage-1 capacity / FPS bounds flags of the chunk
+        self.done = [torch.cuda.Event() for _ in range(3)]
         self._collector = ThreadPoolExecutor(max_workers=1)
         self.stage_threads = max(1, int(stage_threads))
         self.upload_piece = int(upload_piece)                # frames per staging/DMA piece
         self._pool = ThreadPoolExecutor(max_workers=self.stage_threads) if self.stage_threads > 1 else None
+        self._gpool = ThreadPoolExecutor(max_workers=self.stage_threads) if self.stage_threads > 1 else None   # the collector's
 
     def close(self):
         """Stop the staging threads (also called when the runner is garbage-collected)."""
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        if getattr(self, "_gpool", None) is not None:
+            self._gpool.shutdown(wait=True)
+            self._gpool = None
         if getattr(self, "_collector", None) is not None:
             self._collector.shutdown(wait=True)
             self._collector = None
@@ -77,21 +83,12 @@ class EpisodeRunner:
         except Exception:
             pass
 
-    def _stage(self, dst, src):
-        """pageable → pinned copy of the first len(src) frames, split over the staging threads (numpy releases the
-        GIL inside copyto; one memcpy thread does not saturate the host memory system)."""
-        n = src.shape[0]
-        view = dst.numpy()
-        parts = min(self.stage_threads, n) if self._pool is not None else 1
-        if parts <= 1:
-            np.copyto(view[:n], src)
-            return
-        cuts = [n * i // parts for i in range(parts + 1)]
-        list(self._pool.map(lambda ab: np.copyto(view[ab[0]:ab[1]], src[ab[0]:ab[1]]), zip(cuts[:-1], cuts[1:])))
-
-    def _upload(self, slot, depth, rgb):
-        """Stage + upload one chunk in pieces: while the DMA engine moves piece i, the host threads stage piece
-        i+1 into the pinned buffer, so staging and the PCIe transfer overlap instead of adding up."""
+    def _upload(self, slot, rslot, depth, rgb):
+        """Stage + upload one chunk in pieces.  Every piece's pageable → pinned copy is ONE task of the staging pool (numpy
+        releases the GIL inside copyto), all pieces are submitted at once, and the main thread enqueues a piece's H2D copy as
+        soon as that piece is staged: the copies run back to back on the copy stream while later pieces are still being
+        staged, so staging and the PCIe transfer overlap instead of adding up."""
+        import time
         n = depth.shape[0]
         self.uploaded[slot].synchronize()                    # the slot's pinned staging buffer: its last H2D has finished
         if n < self.chunk:                                   # a short tail chunk: invalid depth → empty clouds
@@ -100,17 +97,27 @@ class EpisodeRunner:
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(self.consumed[slot])
             if self.profile:
-                self._ev[slot][0].record(self.copy_stream)
-        import time
-        for a in range(0, max(n, 1), piece):
-            b = min(a + piece, n)
-            if b > a:
-                t0 = time.perf_counter()
-                self._stage(self.h_depth[slot][a:b], depth[a:b])
-                if not self.rgb_on_host:
-                    self._stage(self.h_rgb[slot][a:b], rgb[a:b])
-                self.stats["stage_s"] += time.perf_counter() - t0
-            last = b >= n
+                self._ev[rslot][0].record(self.copy_stream)
+        hd = self.h_depth[slot].numpy()
+        hc = self.h_rgb[slot].numpy() if not self.rgb_on_host else None
+
+        def stage(a, b):
+            np.copyto(hd[a:b], depth[a:b])
+            if hc is not None:
+                np.copyto(hc[a:b], rgb[a:b])
+
+        cuts = list(range(0, n, piece)) + [n] if n > 0 else [0, 0]
+        t0 = time.perf_counter()
+        if self._pool is not None:
+            futs = [self._pool.submit(stage, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        else:
+            futs = None
+        for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+            if futs is not None:
+                futs[k].result()
+            elif b > a:
+                stage(a, b)
+            last = k == len(cuts) - 2
             hi = self.chunk if last else b                   # the last piece carries the zeroed tail too
             with torch.cuda.stream(self.copy_stream):
                 self.d_depth[slot][a:hi].copy_(self.h_depth[slot][a:hi], non_blocking=True)
@@ -118,10 +125,9 @@ class EpisodeRunner:
                     self.d_rgb[slot][a:hi].copy_(self.h_rgb[slot][a:hi], non_blocking=True)
                 if last:
                     if self.profile:
-                        self._ev[slot][1].record(self.copy_stream)
+                        self._ev[rslot][1].record(self.copy_stream)
                     self.uploaded[slot].record(self.copy_stream)
-            if last:
-                break
+        self.stats["stage_s"] += time.perf_counter() - t0
 
     def run_chunks(self, chunks):
         """chunks: iterable of (depth (n,H,W) f32, rgb (n,Hc,Wc,3) u8) with n <= chunk.
@@ -141,45 +147,45 @@ class EpisodeRunner:
             a, b = ab
             out[a:b, :, :3] = xyz[a:b]
             c = cp[a:b]
-            flat = np.ascontiguousarray(rgb[a:b]).reshape((b - a) * hw, 3)
+            flat = np.ascontiguousarray(rgb[a:b]).reshape((b - a) * hw, 3).view("V3").reshape(-1)   # pixels as 3-byte items
             rows = np.maximum(c, 0).astype(np.int64)
             rows += (np.arange(b - a, dtype=np.int64) * hw)[:, None]
-            got = flat[rows.reshape(-1)].reshape(b - a, self.K, 3)     # one row gather: (b-a)*K pixels of 3 bytes
+            got = np.take(flat, rows.reshape(-1)).view(np.uint8).reshape(b - a, self.K, 3)   # one gather of (b-a)*K pixels
             np.multiply(got, (c >= 0)[:, :, None], out=out[a:b, :, 3:], casting="unsafe")
 
-        parts = min(self.stage_threads, n) if self._pool is not None else 1
+        parts = min(self.stage_threads, n) if self._gpool is not None else 1
         if parts <= 1:
             part((0, n))
         else:
             cuts = [n * i // parts for i in range(parts + 1)]
-            list(self._pool.map(part, zip(cuts[:-1], cuts[1:])))
+            list(self._gpool.map(part, zip(cuts[:-1], cuts[1:])))
         return out
 
-    def _collect(self, slot, n, rgb, chunk_no):
-        """Collector thread: wait for chunk `chunk_no`'s results (pinned buffers of `slot`) and turn them into rows
-        while the GPU works on the next chunk."""
+    def _collect(self, rslot, n, rgb, chunk_no):
+        """Collector thread: wait for chunk `chunk_no`'s results (pinned buffers of result slot `rslot`) and turn them into
+        rows while the GPU works on the next chunk."""
         import time
         t0 = time.perf_counter()
-        self.done[slot].synchronize()
+        self.done[rslot].synchronize()
         t1 = time.perf_counter()
-        fl = self.h_flags[slot]
+        fl = self.h_flags[rslot]
         if int(fl[0]) or int(fl[1]):
             raise _ffi.PcpError(-3, "stage-1 row capacity exceeded" if int(fl[0]) else
                                 "a cloud exceeded max_pts / total_pts in pcp_fps_batched")
-        rows = self._host_rows(slot, n, rgb) if self.rgb_on_host else self.h_rows[slot][:n].numpy().copy()
-        counts = np.diff(self.h_off[slot].numpy())[:n]
+        rows = self._host_rows(rslot, n, rgb) if self.rgb_on_host else self.h_rows[rslot][:n].numpy().copy()
+        counts = np.diff(self.h_off[rslot].numpy())[:n]
         st = self.stats
         st["wait_s"] += t1 - t0; st["host_rows_s"] += time.perf_counter() - t1
         st["frames"] += n; st["chunks"] += 1
         if self.profile:                                    # the chunk's events have all completed by now
-            ev = self._ev[slot]
+            ev = self._ev[rslot]
             st["h2d_ms"] += ev[0].elapsed_time(ev[1]); st["kernels_ms"] += ev[2].elapsed_time(ev[3])
             st["d2h_ms"] += ev[3].elapsed_time(ev[4])
         return rows, counts
 
     def _run_chunks(self, chunks):
         """Three things overlap: the GPU runs chunk i, the main thread stages + uploads chunk i+1 (copy stream), the
-        collector thread turns chunk i-1's results into rows.  Every buffer exists twice (slot = chunk parity)."""
+        collector thread turns chunk i-1's results into rows."""
         futures = []
         main = torch.cuda.current_stream(self.dev)
         for s in range(2):
@@ -188,11 +194,11 @@ class EpisodeRunner:
         nxt = next(it, None)
         i = 0
         if nxt is not None:
-            self._upload(0, *nxt)
+            self._upload(0, 0, *nxt)
         while nxt is not None:
-            cur_n, slot = nxt[0].shape[0], i & 1
+            cur_n, slot, rs = nxt[0].shape[0], i & 1, i % 3
             main.wait_event(self.uploaded[slot])
-            ev = self._ev[slot] if self.profile else None
+            ev = self._ev[rs] if self.profile else None
             if ev:
                 ev[2].record(main)
             dsrc = ops.depth_mm_to_m(self.d_depth[slot], self.d_depth_m) if self.depth_mm else self.d_depth[slot]
@@ -201,28 +207,28 @@ class EpisodeRunner:
                 self.consumed[slot].record(main)
                 if ev:
                     ev[3].record(main)
-                self.h_xyz[slot].copy_(xyz, non_blocking=True)
-                self.h_cpix[slot].copy_(cpix, non_blocking=True)
+                self.h_xyz[rs].copy_(xyz, non_blocking=True)
+                self.h_cpix[rs].copy_(cpix, non_blocking=True)
             else:
                 xyz, col, idx, off = self.pipe.run(dsrc, self.d_rgb[slot])
                 packed = ops.pack_dp3(xyz, col)
                 self.consumed[slot].record(main)
                 if ev:
                     ev[3].record(main)
-                self.h_rows[slot].copy_(packed, non_blocking=True)
-            self.h_off[slot].copy_(off, non_blocking=True)
-            self.h_flags[slot][0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
-            self.h_flags[slot][1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
+                self.h_rows[rs].copy_(packed, non_blocking=True)
+            self.h_off[rs].copy_(off, non_blocking=True)
+            self.h_flags[rs][0:1].copy_(self.pipe.stage1.overflow, non_blocking=True)
+            self.h_flags[rs][1:2].copy_(self.pipe.fps.overflow, non_blocking=True)
             if ev:
                 ev[4].record(main)
-            self.done[slot].record(main)
-            futures.append(self._collector.submit(self._collect, slot, cur_n, nxt[1] if self.rgb_on_host else None, i))
+            self.done[rs].record(main)
+            futures.append(self._collector.submit(self._collect, rs, cur_n, nxt[1] if self.rgb_on_host else None, i))
             nxt = next(it, None)
             i += 1
             if nxt is not None:
-                if i >= 2:
-                    futures[i - 2].result()                      # the slot's pinned buffers and events are free again
-                self._upload(i & 1, *nxt)
+                if i >= 3:
+                    futures[i - 3].result()                      # result slot i % 3 (buffers, events) is free again
+                self._upload(i & 1, i % 3, *nxt)
         if not futures:
             return np.zeros((0, self.K, 6), np.float32), np.zeros((0,), np.int64)
         got = [f.result() for f in futures]

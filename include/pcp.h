@@ -218,7 +218,9 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *             3: as 2 with the deferred rounds always on   4: as 2 with them always off
  *             5: as 2 with MULTI-PICK rounds (one workgroup round certifies up to four consecutive picks)
  *             6: as 2 with one pick per round, whatever the batch size
- *                (same indices in every case; 3-6 are for tests and tuning)
+ *             7 / 8: as 5 with the deferred rounds always off / on   9: as 5 with exact-key deferred updates inside the
+ *                multi-pick rounds whatever the batch size
+ *                (same indices in every case; 3-9 are for tests and tuning)
  * `total_pts` is the row count of xyz (and of the workspace).  `max_pts` is an upper bound on the
  * largest cloud (host-known, e.g. H*W): it decides which size-bucketed launch shapes run, never
  * the picks.

@@ -581,6 +581,9 @@ __device__ __forceinline__ void fps_sort_points(const float* __restrict__ P, int
 // pick.  Fewer loads, but a longer instruction chain per flush: it pays while the rounds are bound by
 // fabric bandwidth (many clouds resident, the first few hundred rounds) and not after, so the host
 // passes the number of rounds to run this way and the eager loop takes over from there.
+#ifndef PCP_FPS_MP_DEFER_MIN_B
+#define PCP_FPS_MP_DEFER_MIN_B 128   // multi-pick rounds defer bucket updates that leave the key exact from this many clouds per launch
+#endif
 #ifndef PCP_FPS_LAZY_ALPHA
 #define PCP_FPS_LAZY_ALPHA 0.95f
 #endif
@@ -815,15 +818,30 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
 //   * the picks are certified in parallel: every wave ranks its own top among the sixteen (one ballot), the up to four
 //     best check themselves against the better ones (lanes = waves), write their verdict, and after a second barrier
 //     every wave reads the verdicts: n = 1 + the number of leading certified ranks.
-template <int T, int MODE, int BH>
+template <int T, int MODE, int BH, bool DEFER>
 __device__ __forceinline__ void
 fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
-                     unsigned long long* pkey, float4* pxyz, float4* bxyz, float4* sel, int* okf,
+                     unsigned long long* pkey, float4* pxyz, float4* bxyz, float4* sel, int* okf, float4* ring,
                      long long* __restrict__ irow, float* __restrict__ orow, const int tid, const int lane, const int wave,
                      unsigned long long key, const float (&blo)[3], const float (&bhi)[3], float sx, float sy, float sz)
 {
     constexpr int NW = T / 64, BS = 64 * BH;
     constexpr unsigned long long LOW = (1ull << NW) - 1ull;
+    // DEFERRED UPDATES WITH EXACT KEYS.  A sample that could lower a min-distance of a bucket (it fails the box test) but
+    // does not lower the one of its arg-max ROW leaves the bucket's key exact — every other row only loses min-distance — so
+    // the bucket stays a candidate as it is and its rows need not be touched now: the sample's pick number joins the
+    // bucket's PENDING list (three 10-bit pick numbers + a count in one register of the owning lane; the picks' coordinates
+    // sit in a 1,024-entry LDS ring).  The rows are streamed — all pending samples and the new ones applied in one pass —
+    // when a sample does reach the arg-max row (then the bucket is reduced too), when the list is full, or before a pending
+    // pick number would be overwritten in the ring.  A sample that passes the box test of a bucket can never matter to it
+    // later either: its distance to every row is at least the bucket's maximum of that moment.  On the bench clouds this
+    // halves the buckets streamed per pick (CPU model: 15.3 instead of 28.0, 7.5 instead of 17.3 in the late rounds).
+    // It pays where the fabric is busy — 256 clouds 2.14 -> 1.93 ms, 512 clouds 3.51 -> 3.36 — and costs a little where one
+    // cloud has a CU and its memory path to itself (1 cloud 1.49 -> 1.55 ms: the test phase and the passes grow by the list
+    // handling), so the host turns it on from PCP_FPS_MP_DEFER_MIN_B clouds per launch.
+    constexpr int RING = 1024;
+    unsigned pend = 0u;                                          // [count:2][pick:10][pick:10][pick:10], oldest first
+    float4 smv = make_float4(sx, sy, sz, 0.f);                   // lane i < n: sample i of the round
     unsigned sec = (unsigned)(key >> 32);                        // runner-up VALUE of the bucket, or any upper bound of it
     int n = 1;
     float s[4][3];                                               // the round's samples (wave-uniform)
@@ -842,6 +860,9 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
     for (int round = 0;; ++round) {
         const int par = round & 1;
         STAMP(t0);
+        // every wave keeps its own copy of the ring current: its LDS accesses stay in program order, so its flushes read the
+        // entries back without a barrier (the round's picks are numbers kd-n .. kd-1)
+        if (DEFER && lane < n) ring[(kd - n + lane) & (RING - 1)] = smv;
         // ---- bucket tests by the owning lanes: which samples could change the bucket, and do they reach its arg-max row
         const float4 ps = bxyz[wave * 64 + lane];
         const float cmax = __uint_as_float((unsigned)(key >> 32));
@@ -858,8 +879,22 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
                 hit = hit || (a && dist2<MODE>(s[i][0], s[i][1], s[i][2], ps.x, ps.y, ps.z) < cmax);
             }
         }
-        const unsigned long long amask = __ballot(affb != 0u);
-        const unsigned long long hmask = __ballot(hit);
+        bool flush = affb != 0u;
+        if (DEFER) {
+            const unsigned cnt = pend >> 30;
+            // the oldest pending pick must leave before the ring wraps over it (K > 1,024 only)
+            const bool aged = cnt != 0u && (((unsigned)kd - (pend & 1023u)) & 1023u) > (unsigned)(RING - 16);
+            flush = (affb != 0u && (hit || cnt + (unsigned)__popc(affb) > 3u)) || aged;
+            if (!flush && affb != 0u) {                          // append the affecting samples' pick numbers, in order
+                unsigned c = cnt, w = pend & 0x3fffffffu;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((affb >> i) & 1u) { w |= ((unsigned)(kd - n + i) & 1023u) << (10u * c); c += 1u; }
+                pend = w | (c << 30);
+            }
+        }
+        const unsigned long long amask = __ballot(flush);
+        const unsigned long long hmask = __ballot(flush && hit);
         // the wave's partial changes only if a bucket that is reduced this round could be its top or its runner-up
         const bool rebuild = !cached || __ballot(hit && (unsigned)(key >> 32) >= c2) != 0ull;
         if (rebuild) { cand = 0ull; cand_j = wave; c2 = 0u; }
@@ -905,6 +940,17 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
                     mm[u] = D[r];
                 }
             }
+            // lane 4u+i fetches pending sample i of slot u's bucket (slots past the count read some valid entry, unused)
+            unsigned pw[G];
+            float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (DEFER) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) pw[u] = (unsigned)__builtin_amdgcn_readlane((int)pend, ol[u]);
+                unsigned w = pw[0];
+#pragma unroll
+                for (int u = 1; u < G; ++u) w = (lane >> 2) == u ? pw[u] : w;
+                pm = ring[(w >> (10u * (unsigned)(lane & 3))) & 1023u];
+            }
             if (first && rebuild) {                              // VALU work under the memory latency
                 idle_top2();
 #ifdef PCP_FPS_STAMPS
@@ -920,6 +966,14 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
                 const int r = r0[u] + lane;
                 const unsigned ab = (unsigned)__builtin_amdgcn_readlane((int)affb, ol[u]);   // the samples this bucket needs
                 float m = mm[u];
+                if (DEFER) {
+                    const unsigned np = pw[u] >> 30;             // wave-uniform, 0..3
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i < (int)np)
+                            m = fminf(m, dist2<MODE>(rl(pm.x, 4 * u + i), rl(pm.y, 4 * u + i), rl(pm.z, 4 * u + i),
+                                                     pt[u].x, pt[u].y, pt[u].z));
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if ((ab >> i) & 1u)                          // wave-uniform; fminf keeps m when d is NaN, like `d < m`
@@ -1000,6 +1054,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (DEFER && flush) pend = 0u;                           // streamed: nothing pending any more
         if (first && rebuild) idle_top2();                       // nothing to stream, but no partial yet
         cached = true;
         STAMP(t2);
@@ -1039,6 +1094,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
         STAMP(t5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const float4 sm = sel[par * 4 + (lane & 3)];
+        smv = sm;
         const int okv = okf[par * 4 + (lane & 3)];
         const unsigned okm = (unsigned)(__ballot(okv != 0) & 0xfull);            // bit 0: the arg-max itself, always certain
         n = min(__ffs((int)~okm) - 1, min(4, kn - kd));                          // leading certified ranks
@@ -1070,7 +1126,7 @@ constexpr size_t fps_bucket_lds_bytes()
     return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 8 * 16 + 8 * 4 + 64;
 }
 
-template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false>
+template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false, bool DEFER = false>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
@@ -1359,7 +1415,7 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         static_assert(!MULTI && CPL == 1, "multi-pick rounds are a variant of the wide shape");
         float4* sel = bxyz + NBMAX;                                      // [2][4] a round's picks {x,y,z,bits(idx)}
         int* okf = (int*)(sel + 8);                                      // [2][4] their verdicts
-        fps_multipick_rounds<T, MODE, BH>(k0 + 1, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, irow, orow, tid, lane, wave,
+        fps_multipick_rounds<T, MODE, BH, DEFER>(k0 + 1, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, (float4*)cellcnt, irow, orow, tid, lane, wave,
                                           key[0], blo[0], bhi[0], sx, sy, sz);
     }
 }
@@ -1382,15 +1438,15 @@ fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ off
 // bound by its dependent chain (test -> loads -> arg-max -> barrier -> pick), not by instruction issue, and certifying
 // up to four picks per round cuts the number of chains to a third.  One workgroup per CU = four waves per SIMD, so the
 // kernel may use 128 VGPRs.
-template <int T, int CPL, int MODE, int BH = 1>
+template <int T, int CPL, int MODE, int BH = 1, bool DEFER = false>
 __global__ void __launch_bounds__(T)
 fps_bucket_wide_mp(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                    long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                    float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
                    int* __restrict__ overflow)
 {
-    fps_bucket_body<T, CPL, false, MODE, BH, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
-                                                   m_cap, overflow);
+    fps_bucket_body<T, CPL, false, MODE, BH, true, DEFER>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
+                                                          total_pts, m_cap, overflow);
 }
 
 // The same kernel held to 64 VGPRs / 80 SGPRs (scalar registers spill to VGPR lanes) so that TWO workgroups fit a CU:
@@ -1403,8 +1459,8 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
                     float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
                     int* __restrict__ overflow)
 {
-    fps_bucket_body<T, CPL, false, MODE, BH, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
-                                                   m_cap, overflow);
+    fps_bucket_body<T, CPL, false, MODE, BH, true, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
+                                                         total_pts, m_cap, overflow);
 }
 
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
@@ -1452,7 +1508,7 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int m_cap;                   // largest cloud any launch of this call takes (the top shape's m_hi)
     int* overflow;
     int lazy;
-    int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, -1 = never
+    int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, 2 = always and with deferred updates, -1 = never
     hipStream_t st;
 };
 
@@ -1470,9 +1526,10 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
         kern = fps_bucket_wide<T, CPL, MODE, BH>;
         if constexpr (CPL == 1) {
             if (c.mp >= 0) {
-                if (c.B <= PCP_FPS_MP_MAX_B) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;       // one workgroup per CU
+                if (c.B < PCP_FPS_MP_DEFER_MIN_B && c.mp < 2) kern = fps_bucket_wide_mp<T, CPL, MODE, BH, false>;   // one workgroup per CU
+                else if (c.B <= PCP_FPS_MP_MAX_B) kern = fps_bucket_wide_mp<T, CPL, MODE, BH, true>;
                 else if (BH <= 2) kern = fps_bucket_wide_mp2<T, CPL, MODE, (BH <= 2 ? BH : 1)>;  // two (the quartered-bucket shape spills at 64 VGPRs)
-                else if (c.mp > 0) kern = fps_bucket_wide_mp<T, CPL, MODE, BH>;
+                else if (c.mp > 0) kern = fps_bucket_wide_mp<T, CPL, MODE, BH, true>;
             }
         }
     }
@@ -1537,7 +1594,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
                             void* ws, size_t ws_bytes, hipStream_t st)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
-        algo < 0 || algo > 8)
+        algo < 0 || algo > 9)
         return PCP_ERR_INVALID_ARG;
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
@@ -1551,7 +1608,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
     c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
     c.lazy = (algo == 3 || algo == 8) ? 1 : ((algo == 4 || algo == 7) ? -1 : 0);
-    c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 6 ? -1 : 0);
+    c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 9 ? 2 : (algo == 6 ? -1 : 0));
     c.st = st;
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);

@@ -33,7 +33,7 @@ def test_fps_launch_shape_bounds_both_modes_every_algo():
         for m in (bound - 1, bound, bound + 1):
             cloud = stress_fps.make_cloud(rng, m)
             for K in (33, 150):
-                dm, algo = case & 1, (2, 3, 4, 5, 6)[case % 5]
+                dm, algo = case & 1, (2, 3, 4, 5, 6, 9)[case % 6]
                 case += 1
                 off = torch.tensor([0, m], dtype=torch.int64, device="cuda")
                 xyz, idx = ops.fps_batched(torch.from_numpy(cloud).cuda(), off, K, dist_mode=dm, algo=algo, max_pts=m)
@@ -60,6 +60,22 @@ def test_fps_multi_pick_rounds_equal_the_sequential_picks_on_batches():
             rx, ri = cbind.fps(c, K, dm)
             np.testing.assert_array_equal(idx[b].cpu().numpy(), ri, err_msg=f"trial {trial} cloud {b} M={ms[b]} K={K}")
             np.testing.assert_array_equal(xyz[b].cpu().numpy(), rx)
+
+
+def test_fps_deferred_multi_pick_rounds_incl_ring_wrap():
+    """algo 9: multi-pick rounds with exact-key deferred updates forced on for small batches too, at K beyond the 1,024-entry
+    sample ring (a pending pick must be flushed before the ring wraps over it) and on clouds of every launch shape."""
+    import stress_fps
+    rng = np.random.default_rng(9)
+    for M, K in ((61000, 2500), (61000, 4096), (20000, 3000), (140000, 2600), (270000, 1500), (3000, 3000)):
+        for kind in range(2):
+            cloud = stress_fps.make_cloud(rng, M) if kind else rng.uniform(-0.5, 0.5, (M, 3)).astype(np.float32)
+            dm = kind
+            off = torch.tensor([0, M], dtype=torch.int64, device="cuda")
+            xyz, idx = ops.fps_batched(torch.from_numpy(cloud).cuda(), off, K, dist_mode=dm, algo=9, max_pts=M)
+            rx, ri = cbind.fps(cloud, K, dm)
+            np.testing.assert_array_equal(idx[0].cpu().numpy(), ri, err_msg=f"M={M} K={K} mode={dm}")
+            np.testing.assert_array_equal(xyz[0].cpu().numpy(), rx)
 
 
 @pytest.mark.parametrize("seed", [11, 12])

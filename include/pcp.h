@@ -220,7 +220,12 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *             6: as 2 with one pick per round, whatever the batch size
  *             7 / 8: as 5 with the deferred rounds always off / on   9: as 5 with exact-key deferred updates inside the
  *                multi-pick rounds whatever the batch size
- *                (same indices in every case; 3-9 are for tests and tuning)
+ *            10: as 2 as a QUANTUM-SLICED launch whatever the batch size: one resident workgroup per CU, clouds take
+ *                turns on them a stretch of time at a time.  Algo 0 and 2 launch that way by themselves for batches of a
+ *                little more than one cloud per CU (257-336 clouds on 256 CUs, the 300-frame episode: 2.40 instead of
+ *                2.83 ms); pcp_fps_workspace_bytes then asks for 72 KB more per cloud, where waiting clouds park their
+ *                round state.  3-9 never launch that way.
+ *                (same indices in every case; 3-10 are for tests and tuning)
  * `total_pts` is the row count of xyz (and of the workspace).  `max_pts` is an upper bound on the
  * largest cloud (host-known, e.g. H*W): it decides which size-bucketed launch shapes run, never
  * the picks.
@@ -250,7 +255,9 @@ int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t tot
  * Inputs, outputs, `overflow`, results and every other rule are those of pcp_fps_batched; the call itself makes
  * no hipMalloc / hipFree / allocating library call.  All calls on one GPU share that GPU's array: calls that
  * overlap on the same GPU (different streams or threads) race — serialise them.  Nothing has to be cleared
- * between calls (a launch rewrites every row it reads).
+ * between calls (a launch rewrites every row it reads).  Quantum-sliced launches (algo 10, or 0 / 2 at 257-336
+ * clouds) are not made here — their parked round state would not fit the array — so such a batch runs with two
+ * resident workgroups per CU instead, same results.
  * The FIRST call on a device resolves the array's device address (hipGetSymbolAddress, which may also make the
  * runtime load the code object that holds the 32 MiB array): make that call — or pcp_fps_static_prepare(), which does
  * nothing else — once per device OUTSIDE graph capture, as a warm-up; every later call only enqueues kernels.

@@ -818,12 +818,21 @@ fps_lazy_rounds(const int ks, const int M, const int NB, float4* __restrict__ S,
 //   * the picks are certified in parallel: every wave ranks its own top among the sixteen (one ballot), the up to four
 //     best check themselves against the better ones (lanes = waves), write their verdict, and after a second barrier
 //     every wave reads the verdicts: n = 1 + the number of leading certified ranks.
-template <int T, int MODE, int BH, bool DEFER>
+// What the rounds carry from one round to the next besides the bucket keys: a quantum-sliced launch (below) stops the
+// rounds at a pick number, saves this, and another workgroup goes on from it.
+struct FpsMpCarry {
+    unsigned pend;               // the lane's bucket: pending pick numbers (deferred updates)
+    unsigned sec;                // the lane's bucket: runner-up value or an upper bound of it
+    int n;                       // picks made by the last round = samples the next round applies
+    float4 smv;                  // lane i < n: sample i
+};
+
+template <int T, int MODE, int BH, bool DEFER, bool TIMED = false>
 __device__ __forceinline__ void
-fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
+fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop, const int kn, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
                      unsigned long long* pkey, float4* pxyz, float4* bxyz, float4* sel, int* okf, float4* ring,
                      long long* __restrict__ irow, float* __restrict__ orow, const int tid, const int lane, const int wave,
-                     unsigned long long key, const float (&blo)[3], const float (&bhi)[3], float sx, float sy, float sz)
+                     unsigned long long& key, const float (&blo)[3], const float (&bhi)[3], FpsMpCarry& cy)
 {
     constexpr int NW = T / 64, BS = 64 * BH;
     constexpr unsigned long long LOW = (1ull << NW) - 1ull;
@@ -840,13 +849,13 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
     // cloud has a CU and its memory path to itself (1 cloud 1.49 -> 1.55 ms: the test phase and the passes grow by the list
     // handling), so the host turns it on from PCP_FPS_MP_DEFER_MIN_B clouds per launch.
     constexpr int RING = 1024;
-    unsigned pend = 0u;                                          // [count:2][pick:10][pick:10][pick:10], oldest first
-    float4 smv = make_float4(sx, sy, sz, 0.f);                   // lane i < n: sample i of the round
-    unsigned sec = (unsigned)(key >> 32);                        // runner-up VALUE of the bucket, or any upper bound of it
-    int n = 1;
+    unsigned pend = cy.pend;                                     // [count:2][pick:10][pick:10][pick:10], oldest first
+    float4 smv = cy.smv;                                         // lane i < n: sample i of the round
+    unsigned sec = cy.sec;                                       // runner-up VALUE of the bucket, or any upper bound of it
+    int n = cy.n;
     float s[4][3];                                               // the round's samples (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i][0] = sx; s[i][1] = sy; s[i][2] = sz; }
+    for (int i = 0; i < 4; ++i) { s[i][0] = rl(smv.x, i); s[i][1] = rl(smv.y, i); s[i][2] = rl(smv.z, i); }
     if (tid < 8) okf[tid] = 0;
     unsigned long long cand = 0ull;                              // the wave's best point, its bucket, its rub
     int cand_j = wave;
@@ -859,6 +868,7 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
 #endif
     for (int round = 0;; ++round) {
         const int par = round & 1;
+        const unsigned long long t_now = TIMED ? wall_clock64() : 0ull;      // read here, used by the picker: off its critical path
         STAMP(t0);
         // every wave keeps its own copy of the ring current: its LDS accesses stay in program order, so its flushes read the
         // entries back without a barrier (the round's picks are numbers kd-n .. kd-1)
@@ -1088,7 +1098,11 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
             }
             if (lane == 0) {
                 sel[par * 4 + rank] = make_float4(ox, oy, oz, __int_as_float((int)(~(unsigned)cand)));
-                okf[par * 4 + rank] = ok ? 1 : 0;
+                int v = ok ? 1 : 0;
+                // a timed quantum (sliced launches): the wave that writes the first verdict also says whether time is up,
+                // so that every wave leaves the rounds at the same round
+                if (TIMED && rank == 0 && t_now >= t_stop) v |= 2;
+                okf[par * 4 + rank] = v;
             }
         }
         STAMP(t5);
@@ -1096,7 +1110,8 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
         const float4 sm = sel[par * 4 + (lane & 3)];
         smv = sm;
         const int okv = okf[par * 4 + (lane & 3)];
-        const unsigned okm = (unsigned)(__ballot(okv != 0) & 0xfull);            // bit 0: the arg-max itself, always certain
+        const unsigned okm = (unsigned)(__ballot((okv & 1) != 0) & 0xfull);      // bit 0: the arg-max itself, always certain
+        const bool time_up = TIMED && (__builtin_amdgcn_readlane(okv, 0) & 2) != 0;
         n = min(__ffs((int)~okm) - 1, min(4, kn - kd));                          // leading certified ranks
         if (cand != 0ull && rank < n && lane == 0) {                             // the picked waves write their pick
             irow[kd + rank] = (long long)(int)(~(unsigned)cand);
@@ -1110,8 +1125,9 @@ fps_multipick_rounds(int kd, const int kn, const int M, const int NB, float4* __
 #ifdef PCP_FPS_STAMPS
         { unsigned long long t6; STAMP(t6); sT += t1 - t0; sS += t2 - t1; sP += t3 - t2; sB1 += t4 - t3; sK += t5 - t4; sB2 += t6 - t5; nR += 1; }
 #endif
-        if (kd >= kn) break;
+        if (kd >= k_stop || time_up) break;
     }
+    cy.pend = pend; cy.sec = sec; cy.n = n; cy.smv = smv;
 #ifdef PCP_FPS_STAMPS
     if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 1 || wave == NW - 1))
         printf("[stamps] wave %d M=%d NB=%d picks=%d rounds=%llu | cycles per round: test=%llu stream=%llu publish=%llu barrier1=%llu picker=%llu barrier2+read=%llu | per round: passes=%.2f buckets=%.2f reduced=%.2f rebuilds=%.2f\n",
@@ -1415,8 +1431,10 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
         static_assert(!MULTI && CPL == 1, "multi-pick rounds are a variant of the wide shape");
         float4* sel = bxyz + NBMAX;                                      // [2][4] a round's picks {x,y,z,bits(idx)}
         int* okf = (int*)(sel + 8);                                      // [2][4] their verdicts
-        fps_multipick_rounds<T, MODE, BH, DEFER>(k0 + 1, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, (float4*)cellcnt, irow, orow, tid, lane, wave,
-                                          key[0], blo[0], bhi[0], sx, sy, sz);
+        int kd = k0 + 1;
+        FpsMpCarry cy = {0u, (unsigned)(key[0] >> 32), 1, make_float4(sx, sy, sz, 0.f)};
+        fps_multipick_rounds<T, MODE, BH, DEFER>(kd, kn, 0ull, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, (float4*)cellcnt, irow, orow, tid, lane, wave,
+                                                 key[0], blo[0], bhi[0], cy);
     }
 }
 
@@ -1463,6 +1481,315 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
                                                          total_pts, m_cap, overflow);
 }
 
+// ---- QUANTUM-SLICED launch: a little more clouds than CUs, one workgroup per CU ----------------------------------
+// A batch of a little more than one cloud per CU (the 300-frame episode on 256 CUs) leaves most CUs idle for the last
+// third of a resident launch: 44 CUs host two workgroups, which share the CU's instruction issue and set the pace (256
+// clouds: 1.94 ms, 300 clouds: 2.82 ms).  A cloud's picks are one dependent chain, so the only way to use the idle CUs is
+// to move clouds between CUs over time.  Here G = one workgroup per CU stays resident and runs clouds a QUANTUM of picks
+// at a time.  Workgroup i starts cloud i; the E = B - G extra clouds start in WAITING SLOTS, one per group of
+// workgroups.  Slot j and the workgroups of its group carry the same label (j mod 8 = blockIdx mod 8): workgroups that
+// differ by a multiple of 8 are observed to share an XCD, and with it the L2 that holds the group's clouds — a preference
+// for speed, nothing relies on it.  The 32 workgroups of a label are dealt round-robin over the label's slots.
+// A quantum is a stretch of TIME (the early picks of a cloud cost several times the late ones, and it is run time that
+// has to be shared out evenly), checked once per round by the wave that writes the round's first verdict.
+// At the end of a quantum a workgroup reads its group's slot (one word: cloud and the time it has run
+// pick number); if the waiting cloud is behind its own it claims the slot (compare-and-swap to EMPTY), saves its own
+// cloud's round state (72 KB: bucket keys, boxes, pending lists, arg-max points, the sample ring), publishes it in the
+// slot, and goes on with the other.  So the g workgroups of a group take turns over g + 1 clouds and each cloud runs
+// g / (g + 1) of the time.  A workgroup that has finished a cloud takes whatever waits in any slot (its own label first),
+// and exits when every slot is empty.  No workgroup ever waits for another: a published cloud is picked up at somebody's
+// next quantum end, at the latest by its publisher when that has finished the cloud it took instead.
+// The picks are those of the multi-pick rounds, which do not depend on where a round runs: bit-identical output.
+// Hand-off between workgroups (placement-independent, as inside any launch): plain stores -> every wave drains
+// vmcnt -> workgroup barrier -> one lane's agent-scope release fence (L2 write-back) -> vmcnt -> agent-scope store of
+// the slot word; the claimer's compare-and-swap -> agent-scope acquire (drops this CU's L1) -> vmcnt -> barrier ->
+// plain loads.  The min-distance and record arrays travel the same way (they are the bulk of a cloud's state and stay
+// in place).
+#define PCP_FPS_SLICE_STATE_BYTES (73728 + 256)      // per cloud: arg-max xyz 16K | ring 16K | keys 8K | sec 4K | pend 4K | boxes 24K | header
+#define PCP_FPS_SLICE_MAX_B 1024                     // slot-word packing: 10 bits of cloud number beside the pick number
+#define PCP_FPS_SLICE_MAX_SLOTS 256
+typedef __attribute__((address_space(1))) unsigned int fps_gu32;
+// slot word j: 0 = extra cloud G + j, not started yet; 1 = empty; else 1<<31 | microseconds the cloud has run << 10 | cloud
+#define FPS_SLOT_EMPTY 1u
+
+__device__ __forceinline__ unsigned wave_umin_u32(unsigned v) { return ~wave_umax_u32(~v); }
+
+// Does this launch (clouds of m_lo..m_hi points) have anything to do for cloud c?  The size rule of fps_bucket_body: a
+// cloud out of bounds or beyond every shape belongs to the launch of the top size range, which answers it with a -1 row.
+__device__ __forceinline__ bool fps_cloud_is_mine(const long long* __restrict__ offsets, const int c, const long long total_pts,
+                                                  const int m_cap, const int m_lo, const int m_hi)
+{
+    const long long base = offsets[c], Mll = offsets[c + 1] - base;
+    if (fps_cloud_out_of_bounds(base, Mll, total_pts, m_cap)) return m_hi == m_cap;
+    return Mll >= m_lo && Mll <= m_hi;
+}
+
+// Wave 0, all lanes: the cloud this workgroup runs next.  Returns `cur` when it keeps its cloud (-1: exit), else a cloud
+// whose slot it has CLAIMED (*got = the slot word: 0 = a fresh cloud).
+__device__ __forceinline__ int fps_slice_choose(fps_gu32* slot, const int G, const int E, const int grp,
+                                                const int cur, const int cur_run, const int lead, const int lane,
+                                                unsigned* got, const long long* __restrict__ offsets,
+                                                const long long total_pts, const int m_cap, const int m_lo, const int m_hi)
+{
+    if (E == 0) return cur;
+    if (cur >= 0) {
+        if (grp < 0) return cur;                                 // a label without extra clouds
+        // a busy workgroup: its own group's slot, one look, one try
+        const unsigned w = __hip_atomic_load(slot + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int c = -1, run_c = 0;
+        if (w == 0u) { if (fps_cloud_is_mine(offsets, G + grp, total_pts, m_cap, m_lo, m_hi)) c = G + grp; }   // (a sibling launch's: never started here)
+        else if (w >> 31) { c = (int)(w & 1023u); run_c = (int)((w >> 10) & 0x1fffffu); }
+        if (c < 0 || run_c + lead > cur_run) return cur;         // nothing waits, or not far enough behind to be worth a swap
+        int ok = 0;
+        if (lane == 0) {
+            unsigned e = w;
+            ok = __hip_atomic_compare_exchange_strong(slot + grp, &e, FPS_SLOT_EMPTY, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        }
+        if (!__builtin_amdgcn_readfirstlane(ok)) return cur;     // somebody else of the group took it
+        *got = w;
+        return c;
+    }
+    // an idle workgroup: whatever waits anywhere, its own label's slots first, the cloud furthest behind first
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        unsigned best = 0xffffffffu;
+        unsigned w[PCP_FPS_SLICE_MAX_SLOTS / 64];
+#pragma unroll
+        for (int u = 0; u < PCP_FPS_SLICE_MAX_SLOTS / 64; ++u) {
+            const int j = u * 64 + lane;
+            w[u] = j < E ? __hip_atomic_load(slot + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FPS_SLOT_EMPTY;
+        }
+#pragma unroll
+        for (int u = 0; u < PCP_FPS_SLICE_MAX_SLOTS / 64; ++u) {
+            const int j = u * 64 + lane;
+            unsigned run_c = 0xffffffffu;
+            if (w[u] == 0u) { if (fps_cloud_is_mine(offsets, G + j, total_pts, m_cap, m_lo, m_hi)) run_c = 0u; }
+            else if (w[u] >> 31) run_c = (w[u] >> 10) & 0x1fffffu;
+            if (run_c != 0xffffffffu) {
+                const unsigned far = ((j ^ (int)blockIdx.x) & 7) ? 1u : 0u;
+                best = min(best, (far << 30) | (run_c << 8) | (unsigned)j);
+            }
+        }
+        best = wave_umin_u32(best);
+        if (best == 0xffffffffu) return -1;
+        const int j = (int)(best & 255u);
+        unsigned expect = 0u;
+#pragma unroll
+        for (int u = 0; u < PCP_FPS_SLICE_MAX_SLOTS / 64; ++u)
+            if ((j >> 6) == u) expect = (unsigned)__builtin_amdgcn_readlane((int)w[u], j & 63);
+        int ok = 0;
+        if (lane == 0) {
+            unsigned e = expect;
+            ok = __hip_atomic_compare_exchange_strong(slot + j, &e, FPS_SLOT_EMPTY, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        }
+        if (__builtin_amdgcn_readfirstlane(ok)) {
+            *got = expect;
+            return expect == 0u ? G + j : (int)(expect & 1023u);
+        }
+    }
+    return -1;
+}
+
+template <int T, int MODE, int BH>
+__global__ void __launch_bounds__(T)
+fps_bucket_sliced(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
+                  long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                  float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
+                  int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
+                  const int lead)
+{
+    constexpr int NW = T / 64, NBMAX = T, NCELL = PCP_FPS_NCELL, BS = 64 * BH;
+    static_assert(T == 1024, "the saved state is laid out for 1,024 threads: one bucket, one ring entry per thread");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cellcnt = (int*)smem;
+    float* red = (float*)(cellcnt + NCELL);
+    unsigned long long* pkey = (unsigned long long*)(red + PCP_FPS_RED);
+    float4* pxyz = (float4*)(pkey + 2 * NW);
+    float4* bxyz = pxyz + 2 * NW;
+    float4* sel = bxyz + NBMAX;
+    int* okf = (int*)(sel + 8);
+    int* sh = okf + 8;                                           // [4] the scheduler's verdict for the workgroup
+    float4* ring = (float4*)cellcnt;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    fps_gu32* slot = (fps_gu32*)ctl;
+    const int G = (int)gridDim.x;                                // workgroup i starts cloud i; the host keeps G <= B
+    const int E = B - G;                                         // extra clouds, E <= min(G, slots): they start in the waiting slots
+    const int label = (int)blockIdx.x & 7;
+    const int E_l = E > label ? (E - label + 7) >> 3 : 0;        // slots of this label: label, label + 8, ...
+    const int grp = E_l > 0 ? label + 8 * (((int)blockIdx.x >> 3) % E_l) : -1;
+
+    int cur = -1, kd = 0, kn = 0, M = 0, NB = 0;
+    unsigned long long run_t = 0ull;                             // 10 ns ticks this workgroup's cloud has been worked on, here or elsewhere
+    unsigned long long key = 0ull;
+    float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};
+    FpsMpCarry cy = {0u, 0u, 1, make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4* S = pts4;
+    float* D = md;
+    long long* irow = idx;
+    float* orow = out_xyz;
+    bool first = true;
+
+    for (;;) {
+        const unsigned long long t_top = wall_clock64();
+        // ---- which cloud next (wave 0 decides)
+        if (wave == 0) {
+            int nxt = cur;
+            unsigned got = 0u;
+            if (first) nxt = (int)blockIdx.x;                    // nobody else ever starts cloud blockIdx.x
+            else nxt = fps_slice_choose(slot, G, E, grp, cur, (int)min(run_t / 100ull, 0x1fffffull), lead, lane, &got,
+                                        offsets, total_pts, m_cap, m_lo, m_hi);
+            if (lane == 0) { sh[0] = nxt; sh[1] = (int)got; }
+        }
+        first = false;
+        __syncthreads();
+        const int nxt = sh[0];
+        const unsigned got = (unsigned)sh[1];
+        if (nxt < 0) break;                                      // nothing runnable and no cloud of its own (cur < 0)
+        if (nxt != cur) {
+            if (cur >= 0) {
+                // ---- save and release the cloud this workgroup leaves
+                char* sb = state + (size_t)cur * PCP_FPS_SLICE_STATE_BYTES;
+                ((float4*)sb)[tid] = bxyz[tid];
+                ((float4*)(sb + 16384))[tid] = ring[tid];
+                ((unsigned long long*)(sb + 32768))[tid] = key;
+                ((unsigned*)(sb + 40960))[tid] = cy.sec;
+                ((unsigned*)(sb + 45056))[tid] = cy.pend;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    ((float*)(sb + 49152))[c * T + tid] = blo[c];
+                    ((float*)(sb + 49152))[(3 + c) * T + tid] = bhi[c];
+                }
+                if (tid < 4) ((float4*)(sb + 73728))[tid] = cy.smv;
+                if (tid == 0) {
+                    ((int*)(sb + 73728 + 64))[0] = kd; ((int*)(sb + 73728 + 64))[1] = cy.n;
+                    ((unsigned*)(sb + 73728 + 64))[2] = (unsigned)run_t; ((unsigned*)(sb + 73728 + 64))[3] = (unsigned)(run_t >> 32);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its state stores AND its min-distance stores
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // into the slot this workgroup has just emptied: its own group's
+                    __hip_atomic_store(slot + grp, (1u << 31) | ((unsigned)min(run_t / 100ull, 0x1fffffull) << 10) | (unsigned)cur,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            cur = nxt;
+            const long long base = offsets[cur];
+            const long long Mll = offsets[cur + 1] - base;
+            irow = idx + (size_t)cur * K;
+            orow = out_xyz ? out_xyz + (size_t)cur * K * 3 : nullptr;
+            if (got == 0u) {
+                // ---- a fresh cloud: the prologue of fps_bucket_body
+                run_t = 0ull;
+                const bool bad = fps_cloud_out_of_bounds(base, Mll, total_pts, m_cap);
+                bool mine = true;
+                if (bad) {
+                    if (m_hi != m_cap) mine = false;
+                    else if (tid == 0 && overflow) *overflow = 1;
+                }
+                M = bad ? 0 : (int)Mll;
+                if (!bad && (M < m_lo || M > m_hi)) mine = false;
+                kn = !mine ? 0 : (K < M ? K : (M > 0 ? M : 0));
+                if (mine)
+                    for (int k = kn + tid; k < K; k += T) {              // pytorch3d padding
+                        irow[k] = -1;
+                        if (orow) { orow[3 * k] = 0.f; orow[3 * k + 1] = 0.f; orow[3 * k + 2] = 0.f; }
+                    }
+                kd = kn;                                                 // nothing to run unless set up below
+                if (kn > 0) {
+                    const float* P = xyz + 3 * base;
+                    S = pts4 + base;
+                    D = md + base;
+                    fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
+                    NB = (M + BS - 1) / BS;
+                    const int j = lane * NW + wave;
+                    const int r0 = min(j, NB - 1) * BS;
+                    const int rn = min(BS, M - r0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { blo[c] = INFINITY; bhi[c] = -INFINITY; }
+                    bool nan_pt = false;
+                    for (int i = 0; i < rn; i += 8) {
+                        float4 pt[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) pt[u] = S[r0 + min(i + u, rn - 1)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            blo[0] = fminf(blo[0], pt[u].x); bhi[0] = fmaxf(bhi[0], pt[u].x);
+                            blo[1] = fminf(blo[1], pt[u].y); bhi[1] = fmaxf(bhi[1], pt[u].y);
+                            blo[2] = fminf(blo[2], pt[u].z); bhi[2] = fmaxf(bhi[2], pt[u].z);
+                            nan_pt = nan_pt || !(pt[u].x == pt[u].x && pt[u].y == pt[u].y && pt[u].z == pt[u].z);
+                        }
+                    }
+                    if (nan_pt) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) { blo[c] = -INFINITY; bhi[c] = INFINITY; }
+                    }
+                    key = j < NB ? make_key(FLT_MAX, 0u) : 0ull;
+                    const float sx = P[0], sy = P[1], sz = P[2];
+                    bxyz[tid] = make_float4(sx, sy, sz, 0.f);
+                    if (tid == 0) {
+                        irow[0] = 0;
+                        if (orow) { orow[0] = sx; orow[1] = sy; orow[2] = sz; }
+                    }
+                    cy.pend = 0u; cy.sec = (unsigned)(key >> 32); cy.n = 1; cy.smv = make_float4(sx, sy, sz, 0.f);
+                    kd = 1;
+                }
+            } else {
+                // ---- a cloud another workgroup (or this one, earlier) has worked on
+                if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                M = (int)Mll;
+                kn = K < M ? K : M;
+                NB = (M + BS - 1) / BS;
+                S = pts4 + base;
+                D = md + base;
+                const char* sb = state + (size_t)cur * PCP_FPS_SLICE_STATE_BYTES;
+                bxyz[tid] = ((const float4*)sb)[tid];
+                ring[tid] = ((const float4*)(sb + 16384))[tid];
+                key = ((const unsigned long long*)(sb + 32768))[tid];
+                cy.sec = ((const unsigned*)(sb + 40960))[tid];
+                cy.pend = ((const unsigned*)(sb + 45056))[tid];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    blo[c] = ((const float*)(sb + 49152))[c * T + tid];
+                    bhi[c] = ((const float*)(sb + 49152))[(3 + c) * T + tid];
+                }
+                cy.smv = ((const float4*)(sb + 73728))[lane & 3];
+                // (vector loads: a scalar load could be served from the scalar cache, which no acquire refreshes)
+                kd = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cy.n = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 68), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kd = __builtin_amdgcn_readfirstlane(kd);
+                cy.n = __builtin_amdgcn_readfirstlane(cy.n);
+                const unsigned r0 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 72), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned r1 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 76), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run_t = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r1) << 32) |
+                        (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+            }
+        }
+        // ---- one quantum of rounds
+        if (kd < kn) {
+            const unsigned long long t_in = wall_clock64();
+            // (inlined: as a real call the rounds took their pointers as generic ones — flat loads and stores, which also count
+            //  against the LDS wait in front of every barrier — and ran 6 % slower)
+            fps_multipick_rounds<T, MODE, BH, true, true>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+                                                          sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+        }
+        run_t += wall_clock64() - t_top;
+        if (kd >= kn) {
+            // finished (or not this launch's): its rows are read only after the launch
+            __syncthreads();                                             // every wave is out of the rounds' LDS
+            cur = -1;
+        }
+    }
+}
+
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
 template <int T, int CPL, int MODE>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
@@ -1483,12 +1810,23 @@ static int fps_pick_algo(int algo, int64_t max_pts)
     return max_pts >= 2048 ? 2 : 1;
 }
 
-// workspace: sorted records float4[total] | min_d float[total]
-extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo)
+static size_t fps_base_workspace_bytes(int64_t total_pts)
 {
-    (void)B; (void)K; (void)algo; (void)max_pts;
     if (total_pts < 0) total_pts = 0;
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
+}
+static int fps_slice_mode(int algo) { return algo == 10 ? 1 : ((algo == 0 || algo == 2) ? 0 : -1); }
+static bool fps_slice_wanted(int B, int K, int slice);
+static size_t fps_slice_bytes(int B);
+
+// workspace: sorted records float4[total] | min_d float[total] (| sliced launches: status words | saved round state [B])
+extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo)
+{
+    (void)max_pts;
+    size_t n = fps_base_workspace_bytes(total_pts);
+    // quantum-sliced launches (batches of a little more than one cloud per CU) park the round state of a waiting cloud
+    if (fps_slice_wanted(B, K, fps_slice_mode(algo))) n += fps_slice_bytes(B);
+    return n;
 }
 
 // Launch shapes.  "wide": 16 waves, one bucket per lane — 64 rows for clouds of up to 65,536 points (the 640x480
@@ -1509,8 +1847,80 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int* overflow;
     int lazy;
     int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, 2 = always and with deferred updates, -1 = never
+    int slice;                   // quantum-sliced launch: 0 = by batch size, 1 = always (tests), -1 = never
+    unsigned* slice_ctl;         // [2 shapes][PCP_FPS_SLICE_MAX_B status words + 16 counters], or NULL: the workspace has no room
+    char* slice_state;           // [B][PCP_FPS_SLICE_STATE_BYTES]
     hipStream_t st;
 };
+
+#define PCP_FPS_SLICE_CTL_WORDS (PCP_FPS_SLICE_MAX_SLOTS + 64)
+#ifndef PCP_FPS_SLICE_MIN_B
+#define PCP_FPS_SLICE_MIN_B 257          // sliced launches for batches of more clouds than CUs ...
+#endif
+#ifndef PCP_FPS_SLICE_TOP_B
+#define PCP_FPS_SLICE_TOP_B 336          // ... up to where two resident workgroups per CU do as well (350 clouds: 2.85-2.94 against 2.91 ms)
+#endif
+#define PCP_FPS_SLICE_MIN_K 256
+#ifndef PCP_FPS_SLICE_QUANTUM_US
+#define PCP_FPS_SLICE_QUANTUM_US 150      // 300 clouds, K = 1024: 2.59 / 2.49 / 2.45 / 2.40 / 2.42 / 2.40 ms at 25 / 50 / 100 / 150 / 200 / 300 us
+#endif
+
+static int fps_cu_count()
+{
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        cus[dev] = n > 0 ? n : -1;
+    }
+    return cus[dev] > 0 ? cus[dev] : 0;
+}
+
+static bool fps_slice_wanted(int B, int K, int slice)
+{
+    if (slice < 0 || B > PCP_FPS_SLICE_MAX_B || K >= (1 << 21)) return false;
+    if (slice > 0) return B >= 2 && B <= 960;
+    return B >= PCP_FPS_SLICE_MIN_B && B <= PCP_FPS_SLICE_TOP_B && K >= PCP_FPS_SLICE_MIN_K;
+}
+
+static size_t fps_slice_bytes(int B)
+{
+    return pcp_align256((size_t)2 * PCP_FPS_SLICE_CTL_WORDS * 4) + (size_t)B * PCP_FPS_SLICE_STATE_BYTES;
+}
+
+template <int MODE, int BH>
+static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
+{
+    constexpr int T = 1024;
+    const int cus = fps_cu_count();
+    if (cus <= 0) return PCP_ERR_NO_DEVICE;
+    // forced (tests): fewer workgroups than clouds even for a small batch, so that clouds do change workgroups
+    int grid = c.slice > 0 ? std::max(1, std::min(cus, c.B - c.B / 4)) : std::min(cus, c.B);
+    // short quanta keep a group's clouds close together; a quantum's end costs a slot read (~2 us)
+    int quantum = PCP_FPS_SLICE_QUANTUM_US;
+#ifdef PCP_FPS_SLICE_TUNE            // tuning builds only
+    if (const char* e = getenv("PCP_FPS_SLICE_GRID")) grid = std::max(1, std::min(atoi(e), c.B));
+    if (const char* e = getenv("PCP_FPS_SLICE_Q")) quantum = std::max(1, atoi(e));
+#endif
+    int lead = quantum / 2;
+#ifdef PCP_FPS_SLICE_TUNE
+    if (const char* e = getenv("PCP_FPS_SLICE_LEAD")) lead = atoi(e);
+#endif
+    // every extra cloud needs a workgroup of its group (E <= G) and a waiting slot
+    if (c.B - grid > grid) grid = (c.B + 1) / 2;
+    if (c.B - grid > PCP_FPS_SLICE_MAX_SLOTS || c.K >= (1 << 21)) return PCP_ERR_INVALID_ARG;
+    // more than half a CU's LDS: one workgroup per CU whatever the register count
+    const size_t lds = std::max(fps_bucket_lds_bytes<T, 1>(), (size_t)96 * 1024);
+    auto kern = fps_bucket_sliced<T, MODE, BH>;
+    PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    unsigned* ctl = c.slice_ctl + (size_t)shape * PCP_FPS_SLICE_CTL_WORDS;        // zeroed by fps_batched_impl, both shapes at once
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, c.st, c.xyz, c.offsets, c.B, c.K, c.idx, c.out_xyz, c.pts4, c.md,
+                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, ctl, c.slice_state, quantum * 100, lead);
+    return pcp_launch_status();
+}
+
 
 #ifndef PCP_FPS_MP_MAX_B
 #define PCP_FPS_MP_MAX_B 256     // multi-pick rounds for batches of at most this many clouds (one workgroup per CU)
@@ -1518,6 +1928,10 @@ struct FpsCall {                 // everything a launch needs besides its shape
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
 {
+    if constexpr (!MULTI && CPL == 1 && BH <= 2) {
+        if (c.mp >= 0 && c.slice_ctl && fps_slice_wanted(c.B, c.K, c.slice) && (c.slice > 0 || c.B > fps_cu_count()))
+            return launch_sliced<MODE, BH>(c, m_lo, m_hi, BH - 1);
+    }
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
                  int, int*);
@@ -1591,14 +2005,16 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
 // shared by pcp_fps_batched and its no-allocation twin: argument checks, workspace carve-up, launches
 static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
                             int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
-                            void* ws, size_t ws_bytes, hipStream_t st)
+                            void* ws, size_t ws_bytes, hipStream_t st, bool allow_slice)
 {
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
-        algo < 0 || algo > 9)
+        algo < 0 || algo > 10)
         return PCP_ERR_INVALID_ARG;
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
-    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < pcp_fps_workspace_bytes(B, total_pts, max_pts, K, algo))
+    const size_t base_bytes = fps_base_workspace_bytes(total_pts);
+    const bool slice = allow_slice && fps_slice_wanted(B, K, fps_slice_mode(algo));
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + (slice ? fps_slice_bytes(B) : 0))
         return PCP_ERR_WORKSPACE;
     if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || K == 0) return PCP_OK;
@@ -1609,7 +2025,12 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
     c.lazy = (algo == 3 || algo == 8) ? 1 : ((algo == 4 || algo == 7) ? -1 : 0);
     c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 9 ? 2 : (algo == 6 ? -1 : 0));
+    c.slice = slice ? fps_slice_mode(algo) : -1;
+    c.slice_ctl = slice ? (unsigned*)((char*)ws + base_bytes) : nullptr;
+    c.slice_state = slice ? (char*)ws + base_bytes + pcp_align256((size_t)2 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
     c.st = st;
+    if (slice && fps_pick_algo(algo, max_pts) == 2)              // every waiting slot of both sliced shapes: "extra cloud, not started"
+        PCP_FILL_TRY(c.slice_ctl, 0u, (size_t)2 * PCP_FPS_SLICE_CTL_WORDS, st);
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);
     if (dist_mode == 0)
@@ -1626,7 +2047,7 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
                                float* out_xyz, int32_t* overflow, void* ws, size_t ws_bytes, void* stream)
 {
     return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
-                            ws_bytes, (hipStream_t)stream);
+                            ws_bytes, (hipStream_t)stream, true);
 }
 
 // ---- no-allocation twin of pcp_fps_batched -----------------------------------------------------------------------
@@ -1685,6 +2106,7 @@ extern "C" int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, 
     if (rc != PCP_OK) return rc;
     // Nothing in the workspace has to start at zero: every launch rewrites the records and min-distances of the rows
     // it reads before it reads them, so the previous call's contents are never observed.
+    // (no quantum-sliced launches here: their parked round state would not fit the array beside the records)
     return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
-                            pcp_fps_workspace_bytes(B, total_pts, max_pts, K, algo), (hipStream_t)stream);
+                            fps_base_workspace_bytes(total_pts), (hipStream_t)stream, false);
 }

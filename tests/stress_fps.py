@@ -2,7 +2,7 @@
 """Randomised FPS parity soak (not collected by pytest; run by hand on a GPU box):
    python tests/stress_fps.py [--seconds 150] [--seed 0]
 Random batches of clouds (sizes on both sides of every launch-shape bound, volumes, sheets, lattices with exact
-ties, duplicates), random K, distance mode and algo 2/3/4/5/6/9 (deferred rounds on / off, multi-pick rounds on / off / with exact-key deferral), each cloud checked bit-exact against the C oracle."""
+ties, duplicates), random K, distance mode and algo 2/3/4/5/6/9/10 (deferred rounds on / off, multi-pick rounds on / off / with exact-key deferral, quantum-sliced launch), each cloud checked bit-exact against the C oracle."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "point-cloud-processing_amd")]
@@ -46,7 +46,7 @@ def main(argv=None):
             ms += [int(rng.integers(2048, 6000)) for _ in range(200)]
         clouds = [make_cloud(rng, m) for m in ms]
         K = int(rng.choice([1, 2, 5, 64, 255, 256, 257, 300, 700, 1024, 1500]))
-        dm, algo = int(rng.integers(0, 2)), int(rng.choice([2, 3, 4, 5, 6, 9]))
+        dm, algo = int(rng.integers(0, 2)), int(rng.choice([2, 3, 4, 5, 6, 9, 10]))
         off = np.zeros(len(clouds) + 1, np.int64); off[1:] = np.cumsum([len(c) for c in clouds])
         xyz, idx = ops.fps_batched(torch.from_numpy(np.concatenate(clouds)).cuda(), torch.from_numpy(off).cuda(), K,
                                    dist_mode=dm, algo=algo, max_pts=max(ms))

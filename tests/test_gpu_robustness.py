@@ -23,7 +23,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 10])
 def test_fps_cloud_above_max_pts_is_flagged_not_skipped(algo):
     """pcp_fps_batched with an understated max_pts: the oversized cloud gets an all -1 row and the overflow flag;
     the other clouds are sampled as usual; no output row is left unwritten (idx is pre-filled with a canary)."""
@@ -37,7 +37,7 @@ def test_fps_cloud_above_max_pts_is_flagged_not_skipped(algo):
     xyz, idx = plan.run(dev(np.concatenate(clouds)), dev(off))
     torch.cuda.synchronize()
     idx, xyz = idx.cpu().numpy(), xyz.cpu().numpy()
-    if algo == 2:
+    if algo != 1:
         assert int(plan.overflow.item()) == 1
         assert (idx[1] == -1).all() and (xyz[1] == 0).all()
     else:                                                           # brute force has no size classes: it just samples
@@ -72,7 +72,7 @@ def test_fps_offsets_past_total_pts_are_flagged():
     rng = np.random.default_rng(62)
     pts = rng.uniform(-0.5, 0.5, (9000, 3)).astype(np.float32)
     off = np.array([0, 4000, 9000, 20000], np.int64)                # third cloud claims rows that do not exist
-    for algo in (1, 2):
+    for algo in (1, 2, 10):
         plan = ops.Fps(3, 9000, 20000, 32, "cuda", 0, algo)
         plan.idx.fill_(-7)
         _, idx = plan.run(dev(pts), dev(off))

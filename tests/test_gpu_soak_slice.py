@@ -78,10 +78,46 @@ def test_fps_deferred_multi_pick_rounds_incl_ring_wrap():
             np.testing.assert_array_equal(xyz[0].cpu().numpy(), rx)
 
 
+def test_fps_quantum_sliced_launch_equals_the_sequential_picks():
+    """algo 10: fewer resident workgroups than clouds, clouds change workgroups every 150 us (round state parked in the
+    workspace, agent-scope release / acquire hand-off): ragged batches over both wide launch shapes, empty and tiny clouds,
+    K beyond the sample ring, both distance modes — every cloud against the oracle, and twice in a row (the second call
+    finds the first call's parked state and slot words in the workspace)."""
+    import stress_fps
+    rng = np.random.default_rng(10)
+    for trial in range(5):
+        sizes = [[0, 1, 5, 2049, 61000, 30000, 8000, 61000, 45000, 3000, 64, 65536],
+                 [61000] * 10, [70000, 131072, 3000, 90000, 65537, 20000, 100000], [20000] * 16 + [3],
+                 [61000, 0, 61000, 61000, 61000, 2, 61000]][trial]
+        clouds = [stress_fps.make_cloud(rng, m) if m else np.zeros((0, 3), np.float32) for m in sizes]
+        K = (300, 2500, 700, 1500, 1024)[trial]
+        dm = trial & 1
+        off = np.zeros(len(sizes) + 1, np.int64); off[1:] = np.cumsum(sizes)
+        cat = torch.from_numpy(np.concatenate(clouds)).cuda()
+        plan = ops.Fps(len(sizes), cat.shape[0], max(sizes), K, "cuda", dm, 10)
+        ref = [cbind.fps(c, K, dm) if len(c) else None for c in clouds]
+        for rep in range(2):
+            xyz, idx = plan.run(cat, torch.from_numpy(off).cuda())
+            torch.cuda.synchronize()
+            for b, c in enumerate(clouds):
+                if ref[b] is None:
+                    assert (idx[b] == -1).all()
+                    continue
+                rx, ri = ref[b]
+                np.testing.assert_array_equal(idx[b].cpu().numpy(), ri, err_msg=f"trial {trial} rep {rep} cloud {b} M={sizes[b]} K={K}")
+                np.testing.assert_array_equal(xyz[b].cpu().numpy(), rx)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fps_soak_slice(seed, capsys):
     import stress_fps
     _no_mismatch(stress_fps, 4, seed, capsys)
+
+
+@pytest.mark.parametrize("seed", [41])
+def test_fps_sliced_launch_soak_slice(seed, capsys):
+    import stress_fps_sliced
+    _no_mismatch(stress_fps_sliced, 6, seed, capsys)
 
 
 @pytest.mark.parametrize("seed", [21])

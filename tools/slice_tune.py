@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Developer probe (tuning build -DPCP_FPS_SLICE_TUNE): sliced launch timings over grid / quantum."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "point-cloud-processing_amd"))
+import numpy as np, torch
+from pcp import _ffi, ops, synth
+dev = "cuda"
+H, W = 480, 640
+intr = synth.intrinsics(H, W, 605.0)
+p = _ffi.make_params(intr, intr, apply_crop=True)
+def data(frames):
+    d, c = synth.episode(frames, 0, H, W)
+    s1 = ops.Stage1(frames, H, W, dev, want=("xyz32",))
+    out, off = s1.run(torch.from_numpy(d).to(dev), torch.from_numpy(c).to(dev), p)
+    torch.cuda.synchronize()
+    total = int(off[-1]); return out["xyz32"][:total].clone(), off.clone(), total
+def t(frames, xyz, off, total, K, algo, env):
+    for k in ("PCP_FPS_SLICE_GRID", "PCP_FPS_SLICE_Q", "PCP_FPS_SLICE_LEAD"): os.environ.pop(k, None)
+    os.environ.update(env)
+    plan = ops.Fps(frames, total, H * W, K, dev, 1, algo)
+    plan.run(xyz, off); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); plan.run(xyz, off); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    print(f"B={frames} K={K} algo={algo} {env}: min {min(ts):.3f} ms", flush=True)
+for frames in (264, 336, 352, 368, 384, 400):
+    xyz, off, total = data(frames)
+    for K in (1024, 2500):
+        t(frames, xyz, off, total, K, 5, {})
+        t(frames, xyz, off, total, K, 10, {"PCP_FPS_SLICE_GRID": "256"})

@@ -1592,12 +1592,12 @@ __device__ __forceinline__ int fps_slice_choose(fps_gu32* slot, const int G, con
 }
 
 template <int T, int MODE, int BH>
-__global__ void __launch_bounds__(T)
-fps_bucket_sliced(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
-                  long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
-                  float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
-                  int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
-                  const int lead)
+__device__ __forceinline__ void
+fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
+                long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
+                int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
+                const int lead)
 {
     constexpr int NW = T / 64, NBMAX = T, NCELL = PCP_FPS_NCELL, BS = 64 * BH;
     static_assert(T == 1024, "the saved state is laid out for 1,024 threads: one bucket, one ring entry per thread");
@@ -1789,6 +1789,22 @@ fps_bucket_sliced(const float* __restrict__ xyz, const long long* __restrict__ o
         }
     }
 }
+
+template <int T, int MODE, int BH>
+__global__ void __launch_bounds__(T)
+fps_bucket_sliced(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
+                  long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
+                  float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
+                  int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
+                  const int lead)
+{
+    fps_sliced_body<T, MODE, BH>(xyz, offsets, B, K, idx, out_xyz, pts4, md, m_lo, m_hi, total_pts, m_cap, overflow, ctl, state,
+                                 quantum, lead);
+}
+
+// (Measured and dropped: the same body held to 64 VGPRs / 80 SGPRs with TWO resident workgroups per CU, for batches of a
+//  little more than two clouds per CU — 121 scalar spills and 224 bytes of scratch per lane; 512 clouds on 512 workgroups
+//  4.64 ms against the resident launch's 3.37, 600 clouds 5.40-5.70 against 5.03.)
 
 // "deep" shape (multi-chunk buckets, clouds of more than 64*T*CPL points): register-hungry, 4 waves/SIMD.
 template <int T, int CPL, int MODE>

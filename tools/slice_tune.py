@@ -16,7 +16,7 @@ def data(frames):
     torch.cuda.synchronize()
     total = int(off[-1]); return out["xyz32"][:total].clone(), off.clone(), total
 def t(frames, xyz, off, total, K, algo, env):
-    for k in ("PCP_FPS_SLICE_GRID", "PCP_FPS_SLICE_Q", "PCP_FPS_SLICE_LEAD"): os.environ.pop(k, None)
+    for k in ("PCP_FPS_SLICE_GRID", "PCP_FPS_SLICE_Q", "PCP_FPS_SLICE_LEAD", "PCP_FPS_SLICE_TWO"): os.environ.pop(k, None)
     os.environ.update(env)
     plan = ops.Fps(frames, total, H * W, K, dev, 1, algo)
     plan.run(xyz, off); torch.cuda.synchronize()
@@ -26,8 +26,12 @@ def t(frames, xyz, off, total, K, algo, env):
         e0.record(); plan.run(xyz, off); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     print(f"B={frames} K={K} algo={algo} {env}: min {min(ts):.3f} ms", flush=True)
-for frames in (264, 336, 352, 368, 384, 400):
+for frames in (512, 560, 600, 680):
     xyz, off, total = data(frames)
-    for K in (1024, 2500):
+    for K in (1024,):
         t(frames, xyz, off, total, K, 5, {})
-        t(frames, xyz, off, total, K, 10, {"PCP_FPS_SLICE_GRID": "256"})
+        if frames == 512:
+            t(frames, xyz, off, total, K, 10, {"PCP_FPS_SLICE_GRID": "512", "PCP_FPS_SLICE_TWO": "1"})
+        else:
+            for q in (150, 300, 600):
+                t(frames, xyz, off, total, K, 0, {"PCP_FPS_SLICE_Q": str(q)})

@@ -1832,16 +1832,15 @@ static size_t fps_base_workspace_bytes(int64_t total_pts)
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
 }
 static int fps_slice_mode(int algo) { return algo == 10 ? 1 : ((algo == 0 || algo == 2) ? 0 : -1); }
-static bool fps_slice_wanted(int B, int K, int slice);
+static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts);
 static size_t fps_slice_bytes(int B);
 
 // workspace: sorted records float4[total] | min_d float[total] (| sliced launches: status words | saved round state [B])
 extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_pts, int K, int algo)
 {
-    (void)max_pts;
     size_t n = fps_base_workspace_bytes(total_pts);
     // quantum-sliced launches (batches of a little more than one cloud per CU) park the round state of a waiting cloud
-    if (fps_slice_wanted(B, K, fps_slice_mode(algo))) n += fps_slice_bytes(B);
+    if (fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes(B);
     return n;
 }
 
@@ -1864,7 +1863,7 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int lazy;
     int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, 2 = always and with deferred updates, -1 = never
     int slice;                   // quantum-sliced launch: 0 = by batch size, 1 = always (tests), -1 = never
-    unsigned* slice_ctl;         // [2 shapes][PCP_FPS_SLICE_MAX_B status words + 16 counters], or NULL: the workspace has no room
+    unsigned* slice_ctl;         // [3 wide shapes][PCP_FPS_SLICE_CTL_WORDS slot words], or NULL: the workspace has no room
     char* slice_state;           // [B][PCP_FPS_SLICE_STATE_BYTES]
     hipStream_t st;
 };
@@ -1875,6 +1874,10 @@ struct FpsCall {                 // everything a launch needs besides its shape
 #endif
 #ifndef PCP_FPS_SLICE_TOP_B
 #define PCP_FPS_SLICE_TOP_B 336          // ... up to where two resident workgroups per CU do as well (350 clouds: 2.85-2.94 against 2.91 ms)
+#endif
+#ifndef PCP_FPS_SLICE_TOP_B4
+#define PCP_FPS_SLICE_TOP_B4 512         // quartered buckets (clouds of 131,073-262,144 points): the resident launch there is the one-pick
+                                         // kernel (config 5, K = 8192: 300 clouds 37.4 -> 22.7 ms, 400: 42.4 -> 33.0, 448: 45.3 -> 33.8)
 #endif
 #define PCP_FPS_SLICE_MIN_K 256
 #ifndef PCP_FPS_SLICE_QUANTUM_US
@@ -1894,16 +1897,18 @@ static int fps_cu_count()
     return cus[dev] > 0 ? cus[dev] : 0;
 }
 
-static bool fps_slice_wanted(int B, int K, int slice)
+// (max_pts: clouds beyond 131,072 points — quartered buckets — are sliced up to a larger batch, see PCP_FPS_SLICE_TOP_B4)
+static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts)
 {
     if (slice < 0 || B > PCP_FPS_SLICE_MAX_B || K >= (1 << 21)) return false;
     if (slice > 0) return B >= 2 && B <= 960;
-    return B >= PCP_FPS_SLICE_MIN_B && B <= PCP_FPS_SLICE_TOP_B && K >= PCP_FPS_SLICE_MIN_K;
+    const int top = max_pts > 2 * 65536 ? PCP_FPS_SLICE_TOP_B4 : PCP_FPS_SLICE_TOP_B;
+    return B >= PCP_FPS_SLICE_MIN_B && B <= top && K >= PCP_FPS_SLICE_MIN_K;
 }
 
 static size_t fps_slice_bytes(int B)
 {
-    return pcp_align256((size_t)2 * PCP_FPS_SLICE_CTL_WORDS * 4) + (size_t)B * PCP_FPS_SLICE_STATE_BYTES;
+    return pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) + (size_t)B * PCP_FPS_SLICE_STATE_BYTES;
 }
 
 template <int MODE, int BH>
@@ -1931,7 +1936,7 @@ static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
     const size_t lds = std::max(fps_bucket_lds_bytes<T, 1>(), (size_t)96 * 1024);
     auto kern = fps_bucket_sliced<T, MODE, BH>;
     PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned* ctl = c.slice_ctl + (size_t)shape * PCP_FPS_SLICE_CTL_WORDS;        // zeroed by fps_batched_impl, both shapes at once
+    unsigned* ctl = c.slice_ctl + (size_t)shape * PCP_FPS_SLICE_CTL_WORDS;        // zeroed by fps_batched_impl, all three shapes at once
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, c.st, c.xyz, c.offsets, c.B, c.K, c.idx, c.out_xyz, c.pts4, c.md,
                        m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, ctl, c.slice_state, quantum * 100, lead);
     return pcp_launch_status();
@@ -1944,9 +1949,10 @@ static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
 template <int T, int CPL, bool MULTI, int MODE, int BH = 1>
 static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
 {
-    if constexpr (!MULTI && CPL == 1 && BH <= 2) {
-        if (c.mp >= 0 && c.slice_ctl && fps_slice_wanted(c.B, c.K, c.slice) && (c.slice > 0 || c.B > fps_cu_count()))
-            return launch_sliced<MODE, BH>(c, m_lo, m_hi, BH - 1);
+    if constexpr (!MULTI && CPL == 1) {
+        if (c.mp >= 0 && c.slice_ctl && fps_slice_wanted(c.B, c.K, c.slice, BH == 4 ? 4 * 65536 : 65536) &&
+            (c.slice > 0 || c.B > fps_cu_count()))
+            return launch_sliced<MODE, BH>(c, m_lo, m_hi, BH == 1 ? 0 : (BH == 2 ? 1 : 2));
     }
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
@@ -2029,7 +2035,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     const size_t base_bytes = fps_base_workspace_bytes(total_pts);
-    const bool slice = allow_slice && fps_slice_wanted(B, K, fps_slice_mode(algo));
+    const bool slice = allow_slice && fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts);
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + (slice ? fps_slice_bytes(B) : 0))
         return PCP_ERR_WORKSPACE;
     if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
@@ -2043,10 +2049,10 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 9 ? 2 : (algo == 6 ? -1 : 0));
     c.slice = slice ? fps_slice_mode(algo) : -1;
     c.slice_ctl = slice ? (unsigned*)((char*)ws + base_bytes) : nullptr;
-    c.slice_state = slice ? (char*)ws + base_bytes + pcp_align256((size_t)2 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
+    c.slice_state = slice ? (char*)ws + base_bytes + pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
     c.st = st;
-    if (slice && fps_pick_algo(algo, max_pts) == 2)              // every waiting slot of both sliced shapes: "extra cloud, not started"
-        PCP_FILL_TRY(c.slice_ctl, 0u, (size_t)2 * PCP_FPS_SLICE_CTL_WORDS, st);
+    if (slice && fps_pick_algo(algo, max_pts) == 2)              // every waiting slot of the three sliced shapes: "extra cloud, not started"
+        PCP_FILL_TRY(c.slice_ctl, 0u, (size_t)3 * PCP_FPS_SLICE_CTL_WORDS, st);
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);
     if (dist_mode == 0)

@@ -80,17 +80,18 @@ def test_fps_deferred_multi_pick_rounds_incl_ring_wrap():
 
 def test_fps_quantum_sliced_launch_equals_the_sequential_picks():
     """algo 10: fewer resident workgroups than clouds, clouds change workgroups every 150 us (round state parked in the
-    workspace, agent-scope release / acquire hand-off): ragged batches over both wide launch shapes, empty and tiny clouds,
+    workspace, agent-scope release / acquire hand-off): ragged batches over the three wide launch shapes, empty and tiny clouds,
     K beyond the sample ring, both distance modes — every cloud against the oracle, and twice in a row (the second call
     finds the first call's parked state and slot words in the workspace)."""
     import stress_fps
     rng = np.random.default_rng(10)
-    for trial in range(5):
+    for trial in range(6):
         sizes = [[0, 1, 5, 2049, 61000, 30000, 8000, 61000, 45000, 3000, 64, 65536],
                  [61000] * 10, [70000, 131072, 3000, 90000, 65537, 20000, 100000], [20000] * 16 + [3],
-                 [61000, 0, 61000, 61000, 61000, 2, 61000]][trial]
+                 [61000, 0, 61000, 61000, 61000, 2, 61000],
+                 [150000, 262144, 70000, 200000, 131073, 5000, 240000, 180000]][trial]      # quartered buckets too
         clouds = [stress_fps.make_cloud(rng, m) if m else np.zeros((0, 3), np.float32) for m in sizes]
-        K = (300, 2500, 700, 1500, 1024)[trial]
+        K = (300, 2500, 700, 1500, 1024, 1200)[trial]
         dm = trial & 1
         off = np.zeros(len(sizes) + 1, np.int64); off[1:] = np.cumsum(sizes)
         cat = torch.from_numpy(np.concatenate(clouds)).cuda()

@@ -76,6 +76,9 @@ def config5(F):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--only", type=int, choices=[3, 5], default=None)
     a = ap.parse_args()
-    print(json.dumps(config3(a.frames)), flush=True)
-    print(json.dumps(config5(a.frames)), flush=True)
+    if a.only in (None, 3):
+        print(json.dumps(config3(a.frames)), flush=True)
+    if a.only in (None, 5):
+        print(json.dumps(config5(a.frames)), flush=True)

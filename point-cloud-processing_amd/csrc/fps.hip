@@ -1591,6 +1591,31 @@ __device__ __forceinline__ int fps_slice_choose(fps_gu32* slot, const int G, con
     return -1;
 }
 
+#define PCP_FPS_SLICE_CTL_WORDS (PCP_FPS_SLICE_MAX_SLOTS + 64)    // per sliced shape: the waiting slots, then the number of clouds the shape serves
+
+// Ahead of a call's sliced launches: every waiting slot of the three wide shapes to "extra cloud, not started", and how
+// many clouds each shape has to touch at all — a launch for a size range no cloud of the batch falls into (the host only
+// knows an upper bound of the sizes, so every shape the bound allows is launched) then exits at once instead of walking
+// the slots.
+__global__ void __launch_bounds__(256)
+fps_slice_prep(const long long* __restrict__ offsets, const int B, const long long total_pts, const int m_cap,
+               unsigned* __restrict__ ctl)
+{
+    __shared__ int cnt[3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 3 * PCP_FPS_SLICE_CTL_WORDS; i += 256) ctl[i] = 0u;
+    if (tid < 3) cnt[tid] = 0;
+    __syncthreads();
+    constexpr int W = 64 * 1024;
+    for (int c = tid; c < B; c += 256) {
+#pragma unroll
+        for (int sh = 0; sh < 3; ++sh)
+            if (fps_cloud_is_mine(offsets, c, total_pts, m_cap, sh == 0 ? 0 : (W << (sh - 1)) + 1, W << sh)) atomicAdd(&cnt[sh], 1);
+    }
+    __syncthreads();
+    if (tid < 3) ctl[tid * PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS] = (unsigned)cnt[tid];
+}
+
 template <int T, int MODE, int BH>
 __device__ __forceinline__ void
 fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
@@ -1614,6 +1639,7 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (ctl[PCP_FPS_SLICE_MAX_SLOTS] == 0u) return;              // no cloud of the batch is this shape's (fps_slice_prep)
     fps_gu32* slot = (fps_gu32*)ctl;
     const int G = (int)gridDim.x;                                // workgroup i starts cloud i; the host keeps G <= B
     const int E = B - G;                                         // extra clouds, E <= min(G, slots): they start in the waiting slots
@@ -1868,7 +1894,6 @@ struct FpsCall {                 // everything a launch needs besides its shape
     hipStream_t st;
 };
 
-#define PCP_FPS_SLICE_CTL_WORDS (PCP_FPS_SLICE_MAX_SLOTS + 64)
 #ifndef PCP_FPS_SLICE_MIN_B
 #define PCP_FPS_SLICE_MIN_B 257          // sliced launches for batches of more clouds than CUs ...
 #endif
@@ -2008,6 +2033,10 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     // the top of the size range the launches below cover: a cloud beyond it (the caller understated max_pts) is
     // answered with an all -1 row and the overflow flag by the last launch, never skipped
     c.m_cap = max_pts <= W ? W : (max_pts <= 2 * W ? 2 * W : (max_pts <= split_max ? split_max : 0x7fffffff));
+    if (c.slice_ctl) {           // every waiting slot of the three sliced shapes: "extra cloud, not started"; clouds per shape
+        hipLaunchKernelGGL(fps_slice_prep, dim3(1), dim3(256), 0, c.st, c.offsets, c.B, c.total_pts, c.m_cap, c.slice_ctl);
+        if (pcp_launch_status() != PCP_OK) return PCP_ERR_LAUNCH;
+    }
     int rc = launch_bucket_as<1024, 1, false, MODE>(c, 0, W);
     if (rc != PCP_OK || max_pts <= W) return rc;
     // up to 131,072 / 262,144 points: the same shape with buckets of two / four 64-row parts, streamed side by side
@@ -2051,8 +2080,6 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     c.slice_ctl = slice ? (unsigned*)((char*)ws + base_bytes) : nullptr;
     c.slice_state = slice ? (char*)ws + base_bytes + pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
     c.st = st;
-    if (slice && fps_pick_algo(algo, max_pts) == 2)              // every waiting slot of the three sliced shapes: "extra cloud, not started"
-        PCP_FILL_TRY(c.slice_ctl, 0u, (size_t)3 * PCP_FPS_SLICE_CTL_WORDS, st);
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);
     if (dist_mode == 0)

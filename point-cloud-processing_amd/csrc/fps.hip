@@ -346,6 +346,11 @@ __device__ __forceinline__ float rl(float v, int lane)
 //             critical path).
 // LDS slot of bucket j's arg-max point: wave-major (bucket j belongs to wave j % NW, its (j / NW)-th), so that the owning
 // lanes of one wave read consecutive 16-byte entries — the bucket-major layout put all 64 of them on the same four banks
+#ifndef PCP_FPS_MAXP
+#define PCP_FPS_MAXP 4           // picks one multi-pick round may certify.  8 was measured (CPU model: 296 instead of 350 rounds per 1,023
+                                 // picks): bit-exact, but every round pays for eight samples' worth of registers and unrolled code (108
+                                 // scalar spills in the sliced kernel) - 300 clouds 2.54 instead of 2.40 ms, 1 cloud 1.51 / 1.48, 256: 2.01 / 1.94
+#endif
 #define PCP_BX(j, NW, PER_WAVE) (((j) % (NW)) * (PER_WAVE) + (j) / (NW))
 #define PCP_FPS_RED 128          // floats of LDS scratch: bounding-box partials (6 per wave, <= 16 waves), scan scratch
 #define PCP_FPS_CELL_BITS 12
@@ -827,7 +832,7 @@ struct FpsMpCarry {
     float4 smv;                  // lane i < n: sample i
 };
 
-template <int T, int MODE, int BH, bool DEFER, bool TIMED = false>
+template <int T, int MODE, int BH, bool DEFER, bool TIMED = false, int MAXP = 4>
 __device__ __forceinline__ void
 fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop, const int kn, const int M, const int NB, float4* __restrict__ S, float* __restrict__ D,
                      unsigned long long* pkey, float4* pxyz, float4* bxyz, float4* sel, int* okf, float4* ring,
@@ -853,10 +858,11 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
     float4 smv = cy.smv;                                         // lane i < n: sample i of the round
     unsigned sec = cy.sec;                                       // runner-up VALUE of the bucket, or any upper bound of it
     int n = cy.n;
-    float s[4][3];                                               // the round's samples (wave-uniform)
+    static_assert(MAXP == 4 || MAXP == 8, "picks per round: the verdict tables are indexed by lane & (MAXP - 1)");
+    float s[MAXP][3];                                            // the round's samples (wave-uniform)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i][0] = rl(smv.x, i); s[i][1] = rl(smv.y, i); s[i][2] = rl(smv.z, i); }
-    if (tid < 8) okf[tid] = 0;
+    for (int i = 0; i < MAXP; ++i) { s[i][0] = rl(smv.x, i); s[i][1] = rl(smv.y, i); s[i][2] = rl(smv.z, i); }
+    if (tid < 2 * MAXP) okf[tid] = 0;
     unsigned long long cand = 0ull;                              // the wave's best point, its bucket, its rub
     int cand_j = wave;
     unsigned c2 = 0u;
@@ -879,7 +885,7 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
         unsigned affb = 0u;
         bool hit = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MAXP; ++i) {
             if (i < n) {                                         // wave-uniform
                 const float qx = __builtin_amdgcn_fmed3f(s[i][0], blo[0], bhi[0]);   // clamp(sample, box)
                 const float qy = __builtin_amdgcn_fmed3f(s[i][1], blo[1], bhi[1]);
@@ -898,7 +904,7 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
             if (!flush && affb != 0u) {                          // append the affecting samples' pick numbers, in order
                 unsigned c = cnt, w = pend & 0x3fffffffu;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MAXP; ++i)
                     if ((affb >> i) & 1u) { w |= ((unsigned)(kd - n + i) & 1023u) << (10u * c); c += 1u; }
                 pend = w | (c << 30);
             }
@@ -985,7 +991,7 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
                                                      pt[u].x, pt[u].y, pt[u].z));
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MAXP; ++i) {
                     if ((ab >> i) & 1u)                          // wave-uniform; fminf keeps m when d is NaN, like `d < m`
                         m = fminf(m, dist2<MODE>(s[i][0], s[i][1], s[i][2], pt[u].x, pt[u].y, pt[u].z));
                 }
@@ -1083,8 +1089,8 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
         const float4 cc = pxyz[lane & (NW - 1)];
         const unsigned long long gt = __ballot(kk > cand) & LOW;                 // the waves whose top beats this one's
         const int rank = __popcll(gt);
-        if (wave == 0 && lane < 4) okf[(par ^ 1) * 4 + lane] = 0;                // next round's verdicts start at "no"
-        if (cand != 0ull && rank < 4) {                                          // wave-uniform
+        if (wave == 0 && lane < MAXP) okf[(par ^ 1) * MAXP + lane] = 0;          // next round's verdicts start at "no"
+        if (cand != 0ull && rank < MAXP) {                                       // wave-uniform
             const unsigned hi_own = (unsigned)(cand >> 32);
             const float ox = rl(cc.x, wave), oy = rl(cc.y, wave), oz = rl(cc.z, wave);
             bool ok = true;
@@ -1097,22 +1103,22 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
                 ok = tie == 0ull && bad == 0ull && hi_own != 0u;
             }
             if (lane == 0) {
-                sel[par * 4 + rank] = make_float4(ox, oy, oz, __int_as_float((int)(~(unsigned)cand)));
+                sel[par * MAXP + rank] = make_float4(ox, oy, oz, __int_as_float((int)(~(unsigned)cand)));
                 int v = ok ? 1 : 0;
                 // a timed quantum (sliced launches): the wave that writes the first verdict also says whether time is up,
                 // so that every wave leaves the rounds at the same round
                 if (TIMED && rank == 0 && t_now >= t_stop) v |= 2;
-                okf[par * 4 + rank] = v;
+                okf[par * MAXP + rank] = v;
             }
         }
         STAMP(t5);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const float4 sm = sel[par * 4 + (lane & 3)];
+        const float4 sm = sel[par * MAXP + (lane & (MAXP - 1))];
         smv = sm;
-        const int okv = okf[par * 4 + (lane & 3)];
-        const unsigned okm = (unsigned)(__ballot((okv & 1) != 0) & 0xfull);      // bit 0: the arg-max itself, always certain
+        const int okv = okf[par * MAXP + (lane & (MAXP - 1))];
+        const unsigned okm = (unsigned)(__ballot((okv & 1) != 0) & ((1ull << MAXP) - 1ull));   // bit 0: the arg-max itself, always certain
         const bool time_up = TIMED && (__builtin_amdgcn_readlane(okv, 0) & 2) != 0;
-        n = min(__ffs((int)~okm) - 1, min(4, kn - kd));                          // leading certified ranks
+        n = min(__ffs((int)~okm) - 1, min(MAXP, kn - kd));                       // leading certified ranks
         if (cand != 0ull && rank < n && lane == 0) {                             // the picked waves write their pick
             irow[kd + rank] = (long long)(int)(~(unsigned)cand);
             if (orow) {
@@ -1121,7 +1127,7 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
         }
         kd += n;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s[i][0] = rl(sm.x, i); s[i][1] = rl(sm.y, i); s[i][2] = rl(sm.z, i); }
+        for (int i = 0; i < MAXP; ++i) { s[i][0] = rl(sm.x, i); s[i][1] = rl(sm.y, i); s[i][2] = rl(sm.z, i); }
 #ifdef PCP_FPS_STAMPS
         { unsigned long long t6; STAMP(t6); sT += t1 - t0; sS += t2 - t1; sP += t3 - t2; sB1 += t4 - t3; sK += t5 - t4; sB2 += t6 - t5; nR += 1; }
 #endif
@@ -1138,11 +1144,11 @@ fps_multipick_rounds(int& kd, const int k_stop, const unsigned long long t_stop,
 template <int T, int CPL>
 constexpr size_t fps_bucket_lds_bytes()
 {
-    // cell histogram | red | wave partial keys [2][NW] | their xyz [2][NW] | bucket arg-max xyz [T*CPL] | round picks [2][4] + verdicts [2][4]
-    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 8 * 16 + 8 * 4 + 64;
+    // cell histogram | red | wave partial keys [2][NW] | their xyz [2][NW] | bucket arg-max xyz [T*CPL] | round picks [2][8] + verdicts [2][8]
+    return PCP_FPS_NCELL * 4 + PCP_FPS_RED * 4 + 2 * (T / 64) * 8 + 2 * (T / 64) * 16 + (size_t)T * CPL * 16 + 16 * 16 + 16 * 4 + 64;
 }
 
-template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false, bool DEFER = false>
+template <int T, int CPL, bool MULTI, int MODE, int BH = 1, bool MP = false, bool DEFER = false, int MAXP = 4>
 __device__ __forceinline__ void
 fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
@@ -1429,11 +1435,11 @@ fps_bucket_body(const float* __restrict__ xyz, const long long* __restrict__ off
     if (k0 + 1 >= kn) return;
     if constexpr (MP) {
         static_assert(!MULTI && CPL == 1, "multi-pick rounds are a variant of the wide shape");
-        float4* sel = bxyz + NBMAX;                                      // [2][4] a round's picks {x,y,z,bits(idx)}
-        int* okf = (int*)(sel + 8);                                      // [2][4] their verdicts
+        float4* sel = bxyz + NBMAX;                                      // [2][8] a round's picks {x,y,z,bits(idx)}
+        int* okf = (int*)(sel + 16);                                     // [2][8] their verdicts
         int kd = k0 + 1;
         FpsMpCarry cy = {0u, (unsigned)(key[0] >> 32), 1, make_float4(sx, sy, sz, 0.f)};
-        fps_multipick_rounds<T, MODE, BH, DEFER>(kd, kn, 0ull, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, (float4*)cellcnt, irow, orow, tid, lane, wave,
+        fps_multipick_rounds<T, MODE, BH, DEFER, false, MAXP>(kd, kn, 0ull, kn, M, NB, S, D, pkey, pxyz, bxyz, sel, okf, (float4*)cellcnt, irow, orow, tid, lane, wave,
                                                  key[0], blo[0], bhi[0], cy);
     }
 }
@@ -1463,8 +1469,8 @@ fps_bucket_wide_mp(const float* __restrict__ xyz, const long long* __restrict__ 
                    float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
                    int* __restrict__ overflow)
 {
-    fps_bucket_body<T, CPL, false, MODE, BH, true, DEFER>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
-                                                          total_pts, m_cap, overflow);
+    fps_bucket_body<T, CPL, false, MODE, BH, true, DEFER, PCP_FPS_MAXP>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
+                                                                        total_pts, m_cap, overflow);
 }
 
 // The same kernel held to 64 VGPRs / 80 SGPRs (scalar registers spill to VGPR lanes) so that TWO workgroups fit a CU:
@@ -1633,8 +1639,8 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
     float4* pxyz = (float4*)(pkey + 2 * NW);
     float4* bxyz = pxyz + 2 * NW;
     float4* sel = bxyz + NBMAX;
-    int* okf = (int*)(sel + 8);
-    int* sh = okf + 8;                                           // [4] the scheduler's verdict for the workgroup
+    int* okf = (int*)(sel + 16);
+    int* sh = okf + 16;                                          // [4] the scheduler's verdict for the workgroup
     float4* ring = (float4*)cellcnt;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1688,10 +1694,10 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
                     ((float*)(sb + 49152))[c * T + tid] = blo[c];
                     ((float*)(sb + 49152))[(3 + c) * T + tid] = bhi[c];
                 }
-                if (tid < 4) ((float4*)(sb + 73728))[tid] = cy.smv;
+                if (tid < 8) ((float4*)(sb + 73728))[tid] = cy.smv;
                 if (tid == 0) {
-                    ((int*)(sb + 73728 + 64))[0] = kd; ((int*)(sb + 73728 + 64))[1] = cy.n;
-                    ((unsigned*)(sb + 73728 + 64))[2] = (unsigned)run_t; ((unsigned*)(sb + 73728 + 64))[3] = (unsigned)(run_t >> 32);
+                    ((int*)(sb + 73728 + 128))[0] = kd; ((int*)(sb + 73728 + 128))[1] = cy.n;
+                    ((unsigned*)(sb + 73728 + 128))[2] = (unsigned)run_t; ((unsigned*)(sb + 73728 + 128))[3] = (unsigned)(run_t >> 32);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every wave: its state stores AND its min-distance stores
                 __syncthreads();
@@ -1787,14 +1793,14 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
                     blo[c] = ((const float*)(sb + 49152))[c * T + tid];
                     bhi[c] = ((const float*)(sb + 49152))[(3 + c) * T + tid];
                 }
-                cy.smv = ((const float4*)(sb + 73728))[lane & 3];
+                cy.smv = ((const float4*)(sb + 73728))[lane & 7];
                 // (vector loads: a scalar load could be served from the scalar cache, which no acquire refreshes)
-                kd = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cy.n = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 68), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kd = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 128), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                cy.n = (int)__hip_atomic_load((fps_gu32*)(sb + 73728 + 132), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 kd = __builtin_amdgcn_readfirstlane(kd);
                 cy.n = __builtin_amdgcn_readfirstlane(cy.n);
-                const unsigned r0 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 72), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned r1 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 76), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned r0 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 136), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned r1 = __hip_atomic_load((fps_gu32*)(sb + 73728 + 140), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 run_t = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)r1) << 32) |
                         (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
             }
@@ -1804,7 +1810,7 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
             const unsigned long long t_in = wall_clock64();
             // (inlined: as a real call the rounds took their pointers as generic ones — flat loads and stores, which also count
             //  against the LDS wait in front of every barrier — and ran 6 % slower)
-            fps_multipick_rounds<T, MODE, BH, true, true>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+            fps_multipick_rounds<T, MODE, BH, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
                                                           sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
         }
         run_t += wall_clock64() - t_top;

@@ -56,6 +56,30 @@ def test_argument_validation_without_device():
     assert L.pcp_crop_workspace_bytes(0) >= 256
 
 
+def test_fps_workspace_grows_only_where_launches_are_sliced():
+    """pcp_fps_workspace_bytes: 20 B per point everywhere; plus the parked round state (72.25 KB per cloud + slot words) only
+    for the batches pcp_fps_batched runs as quantum-sliced launches — 257-336 clouds (to 512 when max_pts promises clouds of
+    more than 131,072 points) at K >= 256 with algo 0 / 2, or any batch of 2-960 clouds with algo 10 (pcp.h)."""
+    L = _ffi.load_library()
+    base = L.pcp_fps_workspace_bytes(1, 10 ** 6, 65536, 1024, 5)
+    assert base >= 20 * 10 ** 6
+    state = 73728 + 256
+
+    def extra(B, K, algo, max_pts=65536):
+        return L.pcp_fps_workspace_bytes(B, 10 ** 6, max_pts, K, algo) - base
+
+    for B, K, algo, max_pts, sliced in [(256, 1024, 0, 65536, False), (257, 1024, 0, 65536, True), (300, 1024, 2, 65536, True),
+                                        (336, 2500, 0, 65536, True), (337, 1024, 0, 65536, False), (300, 255, 0, 65536, False),
+                                        (400, 8192, 0, 4 * 65536, True), (512, 8192, 0, 4 * 65536, True), (513, 8192, 0, 4 * 65536, False),
+                                        (300, 1024, 5, 65536, False), (300, 1024, 9, 65536, False), (1, 1024, 10, 65536, False),
+                                        (2, 64, 10, 65536, True), (960, 64, 10, 65536, True), (961, 64, 10, 65536, False)]:
+        e = extra(B, K, algo, max_pts)
+        if sliced:
+            assert B * state <= e <= B * state + 8192, (B, K, algo, e)
+        else:
+            assert e == 0, (B, K, algo, e)
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("PCP_HIP_LIB", str(tmp_path / "nope.so"))
     monkeypatch.setattr(_ffi, "_lib", None)

@@ -1491,15 +1491,15 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
 // A batch of a little more than one cloud per CU (the 300-frame episode on 256 CUs) leaves most CUs idle for the last
 // third of a resident launch: 44 CUs host two workgroups, which share the CU's instruction issue and set the pace (256
 // clouds: 1.94 ms, 300 clouds: 2.82 ms).  A cloud's picks are one dependent chain, so the only way to use the idle CUs is
-// to move clouds between CUs over time.  Here G = one workgroup per CU stays resident and runs clouds a QUANTUM of picks
-// at a time.  Workgroup i starts cloud i; the E = B - G extra clouds start in WAITING SLOTS, one per group of
+// to move clouds between CUs over time.  Here G = one workgroup per CU stays resident and runs clouds a QUANTUM at a
+// time.  Workgroup i starts cloud i; the E = B - G extra clouds start in WAITING SLOTS, one per group of
 // workgroups.  Slot j and the workgroups of its group carry the same label (j mod 8 = blockIdx mod 8): workgroups that
 // differ by a multiple of 8 are observed to share an XCD, and with it the L2 that holds the group's clouds — a preference
 // for speed, nothing relies on it.  The 32 workgroups of a label are dealt round-robin over the label's slots.
 // A quantum is a stretch of TIME (the early picks of a cloud cost several times the late ones, and it is run time that
 // has to be shared out evenly), checked once per round by the wave that writes the round's first verdict.
-// At the end of a quantum a workgroup reads its group's slot (one word: cloud and the time it has run
-// pick number); if the waiting cloud is behind its own it claims the slot (compare-and-swap to EMPTY), saves its own
+// At the end of a quantum a workgroup reads its group's slot (one word: the waiting cloud and the time it has run so
+// far); if that cloud is behind its own it claims the slot (compare-and-swap to EMPTY), saves its own
 // cloud's round state (72 KB: bucket keys, boxes, pending lists, arg-max points, the sample ring), publishes it in the
 // slot, and goes on with the other.  So the g workgroups of a group take turns over g + 1 clouds and each cloud runs
 // g / (g + 1) of the time.  A workgroup that has finished a cloud takes whatever waits in any slot (its own label first),
@@ -1512,7 +1512,7 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
 // plain loads.  The min-distance and record arrays travel the same way (they are the bulk of a cloud's state and stay
 // in place).
 #define PCP_FPS_SLICE_STATE_BYTES (73728 + 256)      // per cloud: arg-max xyz 16K | ring 16K | keys 8K | sec 4K | pend 4K | boxes 24K | header
-#define PCP_FPS_SLICE_MAX_B 1024                     // slot-word packing: 10 bits of cloud number beside the pick number
+#define PCP_FPS_SLICE_MAX_B 1024                     // slot-word packing: 10 bits of cloud number beside 21 bits of run time
 #define PCP_FPS_SLICE_MAX_SLOTS 256
 typedef __attribute__((address_space(1))) unsigned int fps_gu32;
 // slot word j: 0 = extra cloud G + j, not started yet; 1 = empty; else 1<<31 | microseconds the cloud has run << 10 | cloud

@@ -1865,6 +1865,7 @@ static size_t fps_base_workspace_bytes(int64_t total_pts)
 }
 static int fps_slice_mode(int algo) { return algo == 10 ? 1 : ((algo == 0 || algo == 2) ? 0 : -1); }
 static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts);
+static bool fps_split_wanted(int B, int K, int slice, int64_t max_pts);
 static size_t fps_slice_bytes(int B);
 
 // workspace: sorted records float4[total] | min_d float[total] (| sliced launches: status words | saved round state [B])
@@ -1873,6 +1874,7 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
     size_t n = fps_base_workspace_bytes(total_pts);
     // quantum-sliced launches (batches of a little more than one cloud per CU) park the round state of a waiting cloud
     if (fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes(B);
+    else if (fps_split_wanted(B, K, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes((B + 1) / 2);
     return n;
 }
 
@@ -1935,6 +1937,13 @@ static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts)
     if (slice > 0) return B >= 2 && B <= 960;
     const int top = max_pts > 2 * 65536 ? PCP_FPS_SLICE_TOP_B4 : PCP_FPS_SLICE_TOP_B;
     return B >= PCP_FPS_SLICE_MIN_B && B <= top && K >= PCP_FPS_SLICE_MIN_K;
+}
+
+// two sliced launches over the halves of a batch of 513-672 clouds (by batch size only: algo 0 / 2)
+static bool fps_split_wanted(int B, int K, int slice, int64_t max_pts)
+{
+    return slice == 0 && B > 2 * (PCP_FPS_SLICE_MIN_B - 1) && B <= 2 * PCP_FPS_SLICE_TOP_B &&
+           fps_slice_wanted((B + 1) / 2, K, 0, max_pts) && !fps_slice_wanted(B, K, 0, max_pts);
 }
 
 static size_t fps_slice_bytes(int B)
@@ -2059,6 +2068,10 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     return launch_bucket_as<512, 2, true, MODE>(c, split_max + 1, 0x7fffffff);
 }
 
+static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
+                            int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
+                            void* ws, size_t base_bytes, bool slice, hipStream_t st);
+
 // shared by pcp_fps_batched and its no-allocation twin: argument checks, workspace carve-up, launches
 static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
                             int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
@@ -2070,11 +2083,32 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     if ((total_pts > 0 && !xyz) || (B > 0 && K > 0 && !idx)) return PCP_ERR_INVALID_ARG;
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     const size_t base_bytes = fps_base_workspace_bytes(total_pts);
+    // a batch of a little more than two clouds per CU goes as two launches over its halves, each of them sliced (the
+    // resident launch runs the clouds beyond 512 as a second wave: 600 clouds 5.03 ms, two sliced launches of 300: 4.8)
+    if (allow_slice && fps_split_wanted(B, K, fps_slice_mode(algo), max_pts) && fps_pick_algo(algo, max_pts) == 2) {
+        const int h = (B + 1) / 2;
+        if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + fps_slice_bytes(h)) return PCP_ERR_WORKSPACE;
+        if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
+        int rc = fps_launch_batch(xyz, offsets, h, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws, base_bytes,
+                                  true, st);
+        if (rc != PCP_OK) return rc;
+        return fps_launch_batch(xyz, offsets + h, B - h, total_pts, max_pts, K, dist_mode, algo, idx + (size_t)h * K,
+                                out_xyz ? out_xyz + (size_t)h * K * 3 : nullptr, overflow, ws, base_bytes,
+                                fps_slice_wanted(B - h, K, 0, max_pts), st);
+    }
     const bool slice = allow_slice && fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts);
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + (slice ? fps_slice_bytes(B) : 0))
         return PCP_ERR_WORKSPACE;
     if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || K == 0) return PCP_OK;
+    return fps_launch_batch(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws, base_bytes, slice, st);
+}
+
+// the launches for clouds [0, B) of `offsets` (arguments checked, overflow flag cleared by the caller)
+static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
+                            int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
+                            void* ws, size_t base_bytes, bool slice, hipStream_t st)
+{
     FpsCall c;
     c.xyz = xyz; c.offsets = (const long long*)offsets; c.B = B; c.K = K; c.idx = (long long*)idx; c.out_xyz = out_xyz;
     c.pts4 = (float4*)ws;

@@ -70,7 +70,7 @@ def test_fps_workspace_grows_only_where_launches_are_sliced():
 
     for B, K, algo, max_pts, sliced in [(256, 1024, 0, 65536, False), (257, 1024, 0, 65536, True), (300, 1024, 2, 65536, True),
                                         (336, 2500, 0, 65536, True), (337, 1024, 0, 65536, False), (300, 255, 0, 65536, False),
-                                        (400, 8192, 0, 4 * 65536, True), (512, 8192, 0, 4 * 65536, True), (513, 8192, 0, 4 * 65536, False),
+                                        (400, 8192, 0, 4 * 65536, True), (512, 8192, 0, 4 * 65536, True),
                                         (300, 1024, 5, 65536, False), (300, 1024, 9, 65536, False), (1, 1024, 10, 65536, False),
                                         (2, 64, 10, 65536, True), (960, 64, 10, 65536, True), (961, 64, 10, 65536, False)]:
         e = extra(B, K, algo, max_pts)
@@ -78,6 +78,12 @@ def test_fps_workspace_grows_only_where_launches_are_sliced():
             assert B * state <= e <= B * state + 8192, (B, K, algo, e)
         else:
             assert e == 0, (B, K, algo, e)
+    # 513-672 clouds go as two launches over the halves of the batch, each sliced: room for the larger half
+    for B, K, algo, max_pts, half in [(513, 1024, 0, 65536, 257), (600, 1024, 2, 65536, 300), (672, 2500, 0, 65536, 336),
+                                      (600, 1024, 0, 4 * 65536, 300), (673, 1024, 0, 65536, 0), (600, 1024, 5, 65536, 0),
+                                      (600, 128, 0, 65536, 0)]:
+        e = extra(B, K, algo, max_pts)
+        assert (half * state <= e <= half * state + 8192) if half else e == 0, (B, K, algo, max_pts, e)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -109,6 +109,35 @@ def test_fps_quantum_sliced_launch_equals_the_sequential_picks():
                 np.testing.assert_array_equal(xyz[b].cpu().numpy(), rx)
 
 
+def test_fps_batch_of_a_little_more_than_two_clouds_per_cu_goes_as_two_sliced_launches():
+    """513-672 clouds per call (algo 0): two launches over the halves of the batch, each quantum-sliced — equal to the
+    resident launch (algo 5) on every cloud and to the oracle on a sample, with and without out_xyz rows of the second half
+    starting mid-array."""
+    rng = np.random.default_rng(600)
+    for B, K in ((513, 256), (600, 300), (672, 257)):
+        sizes = rng.integers(2048, 5000, B)
+        sizes[B // 2] = 0
+        off = np.zeros(B + 1, np.int64); off[1:] = np.cumsum(sizes)
+        pts = rng.uniform(-0.5, 0.5, (int(off[-1]), 3)).astype(np.float32)
+        cat, offd = torch.from_numpy(pts).cuda(), torch.from_numpy(off).cuda()
+        ref = ops.Fps(B, len(pts), 5000, K, "cuda", 1, 5)
+        rx, ri = ref.run(cat, offd)
+        got = ops.Fps(B, len(pts), 5000, K, "cuda", 1, 0)
+        assert got.ws_bytes > ref.ws_bytes                      # room for the parked state of the larger half
+        got.idx.fill_(-7)
+        gx, gi = got.run(cat, offd)
+        torch.cuda.synchronize()
+        assert int(got.overflow.item()) == 0
+        assert torch.equal(gi, ri) and torch.equal(gx.view(torch.int32), rx.view(torch.int32))
+        for b in (0, B // 2 - 1, B // 2, B // 2 + 1, B - 1):
+            if sizes[b] == 0:
+                assert (gi[b] == -1).all()
+                continue
+            ox, oi = cbind.fps(pts[off[b]:off[b + 1]], K, 1)
+            np.testing.assert_array_equal(gi[b].cpu().numpy(), oi)
+            np.testing.assert_array_equal(gx[b].cpu().numpy(), ox)
+
+
 @pytest.mark.parametrize("seed", [11, 12])
 def test_fps_soak_slice(seed, capsys):
     import stress_fps

@@ -223,8 +223,9 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *            10: as 2 as a QUANTUM-SLICED launch whatever the batch size: one resident workgroup per CU, clouds take
  *                turns on them a stretch of time at a time.  Algo 0 and 2 launch that way by themselves for batches of a
  *                little more than one cloud per CU (257-336 clouds on 256 CUs, the 300-frame episode: 2.40 instead of
- *                2.83 ms; up to 512 clouds when max_pts is beyond 131,072); pcp_fps_workspace_bytes then asks for 72 KB
- *                more per cloud, where waiting clouds park their round state.  3-9 never launch that way.
+ *                2.83 ms; up to 512 clouds when max_pts is beyond 131,072; 513-624 clouds as two such launches over the
+ *                halves of the batch); pcp_fps_workspace_bytes then asks for 72 KB more per cloud (per cloud of the larger
+ *                half), where waiting clouds park their round state.  3-9 never launch that way.
  *                (same indices in every case; 3-10 are for tests and tuning)
  * `total_pts` is the row count of xyz (and of the workspace).  `max_pts` is an upper bound on the
  * largest cloud (host-known, e.g. H*W): it decides which size-bucketed launch shapes run, never

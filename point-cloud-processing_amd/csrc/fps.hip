@@ -1939,10 +1939,14 @@ static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts)
     return B >= PCP_FPS_SLICE_MIN_B && B <= top && K >= PCP_FPS_SLICE_MIN_K;
 }
 
-// two sliced launches over the halves of a batch of 513-672 clouds (by batch size only: algo 0 / 2)
+// two sliced launches over the halves of a batch of 513-624 clouds (by batch size only: algo 0 / 2).  Measured, K = 1024,
+// resident launch -> two sliced ones: 513 clouds 4.86 -> 4.17 ms, 560: 4.95 -> 4.59, 600: 5.00 -> 4.83, 672: 5.11 -> 5.38
+#ifndef PCP_FPS_SPLIT_TOP_B
+#define PCP_FPS_SPLIT_TOP_B 624
+#endif
 static bool fps_split_wanted(int B, int K, int slice, int64_t max_pts)
 {
-    return slice == 0 && B > 2 * (PCP_FPS_SLICE_MIN_B - 1) && B <= 2 * PCP_FPS_SLICE_TOP_B &&
+    return slice == 0 && B > 2 * (PCP_FPS_SLICE_MIN_B - 1) && B <= PCP_FPS_SPLIT_TOP_B &&
            fps_slice_wanted((B + 1) / 2, K, 0, max_pts) && !fps_slice_wanted(B, K, 0, max_pts);
 }
 
@@ -2084,7 +2088,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
     if (max_pts > 0x7fffffffLL) return PCP_ERR_INVALID_ARG;
     const size_t base_bytes = fps_base_workspace_bytes(total_pts);
     // a batch of a little more than two clouds per CU goes as two launches over its halves, each of them sliced (the
-    // resident launch runs the clouds beyond 512 as a second wave: 600 clouds 5.03 ms, two sliced launches of 300: 4.8)
+    // resident launch runs the clouds beyond 512 as a second wave: 600 clouds 5.00 ms, two sliced launches of 300: 4.83)
     if (allow_slice && fps_split_wanted(B, K, fps_slice_mode(algo), max_pts) && fps_pick_algo(algo, max_pts) == 2) {
         const int h = (B + 1) / 2;
         if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + fps_slice_bytes(h)) return PCP_ERR_WORKSPACE;

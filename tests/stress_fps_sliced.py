@@ -27,7 +27,7 @@ def main(argv=None):
         auto = rng.random() < 0.6
         B = int(rng.integers(257, 337)) if auto else int(rng.integers(2, 120))
         if auto and rng.random() < 0.15:
-            B = int(rng.integers(513, 673))                             # two launches over the halves of the batch
+            B = int(rng.integers(513, 625))                             # two launches over the halves of the batch
         top = int(rng.choice([6000, 30000, 65536, 100000])) if not auto else int(rng.choice([8000, 30000, 65536]))
         sizes = rng.integers(2048, top + 1, B)
         sizes[rng.integers(0, B)] = top

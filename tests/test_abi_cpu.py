@@ -78,9 +78,9 @@ def test_fps_workspace_grows_only_where_launches_are_sliced():
             assert B * state <= e <= B * state + 8192, (B, K, algo, e)
         else:
             assert e == 0, (B, K, algo, e)
-    # 513-672 clouds go as two launches over the halves of the batch, each sliced: room for the larger half
-    for B, K, algo, max_pts, half in [(513, 1024, 0, 65536, 257), (600, 1024, 2, 65536, 300), (672, 2500, 0, 65536, 336),
-                                      (600, 1024, 0, 4 * 65536, 300), (673, 1024, 0, 65536, 0), (600, 1024, 5, 65536, 0),
+    # 513-624 clouds go as two launches over the halves of the batch, each sliced: room for the larger half
+    for B, K, algo, max_pts, half in [(513, 1024, 0, 65536, 257), (600, 1024, 2, 65536, 300), (624, 2500, 0, 65536, 312),
+                                      (600, 1024, 0, 4 * 65536, 300), (625, 1024, 0, 65536, 0), (600, 1024, 5, 65536, 0),
                                       (600, 128, 0, 65536, 0)]:
         e = extra(B, K, algo, max_pts)
         assert (half * state <= e <= half * state + 8192) if half else e == 0, (B, K, algo, max_pts, e)

@@ -110,11 +110,11 @@ def test_fps_quantum_sliced_launch_equals_the_sequential_picks():
 
 
 def test_fps_batch_of_a_little_more_than_two_clouds_per_cu_goes_as_two_sliced_launches():
-    """513-672 clouds per call (algo 0): two launches over the halves of the batch, each quantum-sliced — equal to the
+    """513-624 clouds per call (algo 0): two launches over the halves of the batch, each quantum-sliced — equal to the
     resident launch (algo 5) on every cloud and to the oracle on a sample, with and without out_xyz rows of the second half
     starting mid-array."""
     rng = np.random.default_rng(600)
-    for B, K in ((513, 256), (600, 300), (672, 257)):
+    for B, K in ((513, 256), (600, 300), (624, 257)):
         sizes = rng.integers(2048, 5000, B)
         sizes[B // 2] = 0
         off = np.zeros(B + 1, np.int64); off[1:] = np.cumsum(sizes)

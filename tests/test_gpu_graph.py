@@ -91,19 +91,21 @@ def test_static_entry_point_records_into_a_hip_graph():
         assert torch.equal(idx, ref.idx) and torch.equal(out, ref.xyz)
 
 
-def test_every_fps_launch_shape_records_into_a_hip_graph():
+@pytest.mark.parametrize("algo", [0, 10])
+def test_every_fps_launch_shape_records_into_a_hip_graph(algo):
     """max_pts > 262,144 makes pcp_fps_batched launch all four bucket shapes (wide, halved, quartered buckets, deep — the
     deep one raises its dynamic-LDS limit with hipFuncSetAttribute on every launch): record them, replay on other clouds
-    of the same sizes, compare with the eager call."""
+    of the same sizes, compare with the eager call.  algo 10: the three wide shapes as quantum-sliced launches (slot prep
+    kernel, 96 KB of dynamic LDS set under capture, clouds changing workgroups during the replay)."""
     rng = np.random.default_rng(9)
-    sizes = [3000, 70000, 140000, 270000, 64]
-    K = 96
+    sizes = [3000, 70000, 140000, 270000, 64, 60000, 61000, 100000]
+    K = 96 if algo == 0 else 700
     off = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).cuda()
     total = int(sum(sizes))
     sets = [np.concatenate([rng.uniform(-1, 1, (m, 3)) * rng.uniform(0.2, 1.0, 3) for m in sizes]).astype(np.float32)
             for _ in range(2)]
     xyz = torch.from_numpy(sets[0]).cuda()
-    plan = ops.Fps(len(sizes), total, 300000, K, "cuda", 1, 0)
+    plan = ops.Fps(len(sizes), total, 300000, K, "cuda", 1, algo)
     refs = []
     for s_ in sets:
         xyz.copy_(torch.from_numpy(s_))

@@ -82,7 +82,7 @@ def _process_traj(data_root, traj, source, K, frame_skip, intr, ext, runner_box)
     return rows, action, state
 
 
-def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=None, encoded=None):
+def assemble(lengths, produce, out_zarr, compressor="blosc", threads=8, timing=None, encoded=None):
     """The dataset-level loop of BASELINE configs[3] (S2:34-45 + CHK:47-200) for any episode source.
       lengths[i]  expected frame count of episode i (only used to balance the ranks)
       produce(i)  → None (episode skipped, CHK:67-70 / 127-132) or (rows (n,K,6), action (n,7), state (n,7))
@@ -150,7 +150,7 @@ def assemble(lengths, produce, out_zarr, compressor="zlib", threads=8, timing=No
     return int(sum(counts)), len(kept)
 
 
-def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, compressor="zlib", intr=None,
+def build(data_root, out_zarr, source="ply", K=2500, frame_skip=FRAME_SKIP, compressor="blosc", intr=None,
           ext=None):
     """source='ply': read <traj>/filtered_point_clouds (the reference's route).
     source='gpu': run depth+rgb of <traj>/extracted_data/<traj> through the GPU path directly.
@@ -198,12 +198,15 @@ def main():
     ap.add_argument("--out_zarr", required=True)
     ap.add_argument("--source", choices=("ply", "gpu"), default="ply")
     ap.add_argument("--num_points", type=int, default=2500)
+    ap.add_argument("--compressor", choices=("blosc", "zlib", "none"), default="blosc",
+                    help="blosc = the reference's Blosc-zstd (chunking_data.py:180); zlib; none")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:                                   # launched by torch.distributed.run: one process per GPU
         import torch.distributed as dist
         dist.init_process_group("gloo")             # host-side object gather only; no data-path collective
-    n, e = build(a.data_root, a.out_zarr, a.source, a.num_points)
+    n, e = build(a.data_root, a.out_zarr, a.source, a.num_points,
+                 compressor=None if a.compressor == "none" else a.compressor)
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"Saved Zarr file: {a.out_zarr}  ({n} frames, {e} episodes)")
     if world > 1:

@@ -29,7 +29,7 @@ class SyntheticEpisodes:
         return depth, rgb, state, action
 
 
-def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", threads=None, rgb_on_host=True, params=None,
+def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="blosc", threads=None, rgb_on_host=True, params=None,
         prefetch=4, warmup=True):
     """Stream every episode of `source` this rank owns through the GPU path and assemble the store.
     Returns dict(frames, episodes, seconds by phase, rates) — this rank's view; frames / episodes are global."""
@@ -57,7 +57,7 @@ def run(source, out_zarr, K=1024, chunk=150, device=None, compressor="zlib", thr
     mine = shard.assign_contiguous(source.lengths, world)[rank]        # the same deal assemble() makes
     ddt = np.uint16 if source.depth_mm else np.float32
     ready = {}
-    # Chunks are ENCODED (zlib) in the background while the GPU works on the next episodes, under the assumption that no
+    # Chunks are ENCODED (Blosc-zstd or zlib) in the background while the GPU works on the next episodes, under the assumption that no
     # episode is skipped — then episode i starts at row sum(lengths[:i]) and a group's rows fill known chunks; assemble()
     # uses them only if the assumption held for every episode of every rank, and encodes the rest (group seams) itself.
     from concurrent.futures import ThreadPoolExecutor

@@ -94,13 +94,13 @@ def stack_for_zarr(episodes):
     return np.concatenate(episodes, axis=0).astype(np.float32), ends
 
 
-def write_rows_sharded(path, local, counts, tail_shape, chunk_rows=100, dtype="<f4", compressor="zlib", threads=8,
+def write_rows_sharded(path, local, counts, tail_shape, chunk_rows=100, dtype="<f4", compressor="blosc", threads=8,
                        group=None, encoded=None):
     """Write ONE zarr array of shape (sum(counts),) + tail_shape, chunked (chunk_rows,) + tail_shape (CHK:188), whose
     rows are the concatenation of the episodes' blocks in episode order, from blocks that live on different ranks.
       local  {episode: ndarray (counts[episode],) + tail_shape} — this rank's episodes
       counts rows of EVERY episode (0 = skipped), the same list on every rank
-    Every rank compresses and writes the chunks that its own rows fill completely (thread pool; zlib releases the
+    Every rank compresses and writes the chunks that its own rows fill completely (thread pool; the codecs release the
     GIL).  Pieces of chunks shared with another rank go to rank 0, which assembles those few chunks and writes
     .zarray.  The directory must exist on a file system all ranks see (one node, BASELINE configs[3]).
     encoded: {chunk index: bytes} — chunks of this rank that the caller has ALREADY encoded (same rows, same chunk grid,

@@ -6,16 +6,21 @@ chunking_data.py creates (CHK:179-200):
     <root>/data/state        (T,7)   float32   chunks (100,7)
     <root>/meta/episode_ends (E,)    int64     chunks (E,)
 
-zarr / numcodecs are not installed here, so the store is written by hand.  The reference
-compresses with Blosc-zstd (CHK:180), which needs numcodecs; this writer uses the zarr-v2
-built-in `zlib` codec (readable by any zarr installation) or no compressor at all.  Array
-names, shapes, dtypes, chunking, C order and fill value are the reference's."""
+zarr / numcodecs are not installed here, so the store is written by hand.  Compressors: "blosc" = the
+reference's `zarr.Blosc(cname='zstd', clevel=3, shuffle=1)` (CHK:180) — Blosc-1 frames written by
+`blosc_frame.py` around pyarrow's zstd codec, the default of the dataset builders; "zlib" = the zarr-v2 built-in
+codec (no dependency beyond the standard library); None = raw chunks.  Array names, shapes, dtypes,
+chunking, C order and fill value are the reference's."""
 import json
 import os
 import shutil
 import zlib
 
 import numpy as np
+
+from . import blosc_frame
+
+BLOSC = {"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": 1, "blocksize": 0}     # CHK:180 as numcodecs writes it
 
 
 def _compressor_meta(compressor):
@@ -25,7 +30,9 @@ def _compressor_meta(compressor):
         # level 1: the rows are float32 coordinates (high-entropy mantissas), level 3 gains 1-2 % of size for twice the
         # CPU time, and compression is what bounds a dataset-mode run once the GPU path is in place
         return {"id": "zlib", "level": 1}
-    raise ValueError("compressor must be None or 'zlib'")
+    if compressor == "blosc":
+        return dict(BLOSC)
+    raise ValueError("compressor must be None, 'zlib' or 'blosc'")
 
 
 def _write_json(path, obj):
@@ -45,7 +52,7 @@ def chunk_grid(shape, chunks):
     return chunks, [-(-s // c) for s, c in zip(shape, chunks)]
 
 
-def write_zarray(path, shape, chunks, dtype, compressor="zlib"):
+def write_zarray(path, shape, chunks, dtype, compressor="blosc"):
     """Create the array directory and its .zarray; returns (meta, effective chunk shape)."""
     chunks, _ = chunk_grid(shape, chunks)
     os.makedirs(path, exist_ok=True)
@@ -57,12 +64,15 @@ def write_zarray(path, shape, chunks, dtype, compressor="zlib"):
     return meta, chunks
 
 
-def encode_chunk(block, compressor="zlib"):
+def encode_chunk(block, compressor="blosc"):
     """The bytes of one chunk file from a FULL-chunk-shaped block (edge chunks zero-padded by the caller)."""
-    raw = np.ascontiguousarray(block).tobytes()
+    block = np.ascontiguousarray(block)
+    raw = block.tobytes()
     comp = _compressor_meta(compressor)
-    if comp:
-        raw = zlib.compress(raw, comp["level"])                 # releases the GIL: chunks compress in parallel threads
+    if comp and comp["id"] == "blosc":                          # numcodecs hands Blosc the array's item size as type size
+        raw = blosc_frame.compress(raw, block.dtype.itemsize, comp["clevel"], comp["shuffle"])
+    elif comp:
+        raw = zlib.compress(raw, comp["level"])                 # both release the GIL: chunks compress in parallel threads
     return raw
 
 
@@ -71,12 +81,12 @@ def write_chunk_bytes(path, cidx, raw):
         fh.write(raw)
 
 
-def write_chunk(path, cidx, block, compressor="zlib"):
+def write_chunk(path, cidx, block, compressor="blosc"):
     """One chunk file "i.j.k" from a FULL-chunk-shaped C-contiguous block."""
     write_chunk_bytes(path, cidx, encode_chunk(block, compressor))
 
 
-def write_array(path, data, chunks, dtype, compressor="zlib", threads=1):
+def write_array(path, data, chunks, dtype, compressor="blosc", threads=1):
     """One zarr-v2 array: .zarray + one file per chunk ("i.j.k"), edge chunks zero-padded.  threads > 1 compresses and
     writes the chunks on a thread pool."""
     data = np.asarray(data)
@@ -120,9 +130,12 @@ def read_array(path):
         raw = open(fn, "rb").read()
         comp = meta["compressor"]
         if comp:
-            if comp["id"] != "zlib":
+            if comp["id"] == "blosc":
+                raw = blosc_frame.decompress(raw)
+            elif comp["id"] == "zlib":
+                raw = zlib.decompress(raw)
+            else:
                 raise ValueError(f"unsupported compressor {comp['id']}")
-            raw = zlib.decompress(raw)
         block = np.frombuffer(raw, dtype=dt).reshape(chunks)
         sl = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(cidx, chunks, shape))
         out[sl] = block[tuple(slice(0, s.stop - s.start) for s in sl)]
@@ -139,7 +152,7 @@ def create_dp3_layout(out_zarr):
     create_group(os.path.join(out_zarr, "meta"))
 
 
-def write_dp3_small_arrays(out_zarr, action, state, episode_ends, chunk_size=100, compressor="zlib"):
+def write_dp3_small_arrays(out_zarr, action, state, episode_ends, chunk_size=100, compressor="blosc"):
     """data/action, data/state, meta/episode_ends (CHK:196-200)."""
     action, state = np.asarray(action), np.asarray(state)
     episode_ends = np.asarray(episode_ends, dtype=np.int64)
@@ -149,7 +162,7 @@ def write_dp3_small_arrays(out_zarr, action, state, episode_ends, chunk_size=100
                 "<i8", compressor)                                                     # CHK:200
 
 
-def write_dp3_dataset(out_zarr, point_cloud, action, state, episode_ends, chunk_size=100, compressor="zlib", threads=1):
+def write_dp3_dataset(out_zarr, point_cloud, action, state, episode_ends, chunk_size=100, compressor="blosc", threads=1):
     """CHK:175-200: overwrite <out_zarr> with the DP3 layout."""
     create_dp3_layout(out_zarr)
     point_cloud = np.asarray(point_cloud)

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--f32-depth", action="store_true", help="upload float32 metres instead of raw u16 millimetres")
     ap.add_argument("--device-rgb", action="store_true", help="upload rgb and gather colours on the device")
-    ap.add_argument("--compressor", default="zlib", choices=["zlib", "none"])
+    ap.add_argument("--compressor", default="blosc", choices=["blosc", "zlib", "none"])
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -48,7 +48,7 @@ def main():
         wall = max(p["wall_s"] for p in parts)
         pipe = max(p["wall_s"] - p["source_s"] for p in parts)
         line = dict(metric="frames/sec, dataset mode (episodes -> zarr)", frames=res["frames"], episodes=res["episodes"],
-                    n_ranks=world, n_gpus=min(world, torch.cuda.device_count()), K=a.K, chunk=a.chunk,
+                    n_ranks=world, n_gpus=min(world, torch.cuda.device_count()), K=a.K, chunk=a.chunk, compressor=a.compressor,
                     depth="u16 mm" if not a.f32_depth else "f32 m", rgb="host" if not a.device_rgb else "device",
                     frames_per_s_wall=res["frames"] / wall, frames_per_s_pipeline=res["frames"] / pipe,
                     breakdown_s_max_over_ranks={k: max(p[k] for p in parts) for k in

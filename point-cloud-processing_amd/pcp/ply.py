@@ -59,8 +59,9 @@ def read_point_cloud(path):
                 props.append((tok[2], tok[1]))
             elif tok[0] == "end_header":
                 break
-        if fmt == "binary_little_endian":
-            dt = np.dtype([(name, _TYPES[t]) for name, t in props])
+        if fmt in ("binary_little_endian", "binary_big_endian"):   # Open3D's reader (rply) takes both
+            order = "<" if fmt == "binary_little_endian" else ">"
+            dt = np.dtype([(name, _TYPES[t].replace("<", order)) for name, t in props])
             rec = np.frombuffer(fh.read(n * dt.itemsize), dtype=dt, count=n)
             col = lambda k: rec[k]
         elif fmt == "ascii":

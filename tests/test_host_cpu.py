@@ -40,6 +40,14 @@ def test_ply_empty_ascii_and_xyz_only(tmp_path):
                  "property float z\nend_header\n1 2 3\n4 5 6\n")
     pts, col = ply.read_point_cloud(str(a))
     assert col is None and pts.tolist() == [[1, 2, 3], [4, 5, 6]]
+    # big-endian files with float coordinates (other writers; Open3D's reader takes them too)
+    rec = np.zeros(3, dtype=[("x", ">f4"), ("y", ">f4"), ("z", ">f4"), ("red", "u1"), ("green", "u1"), ("blue", "u1")])
+    rec["x"], rec["y"], rec["z"], rec["green"] = [0.5, -1.25, 3.0], [1, 2, 3], [7, 8, 9], [0, 51, 255]
+    head = ("ply\nformat binary_big_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+            "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n").encode()
+    (tmp_path / "be.ply").write_bytes(head + rec.tobytes())
+    pts, col = ply.read_point_cloud(str(tmp_path / "be.ply"))
+    assert pts.tolist() == [[0.5, 1, 7], [-1.25, 2, 8], [3.0, 3, 9]] and col[:, 1].tolist() == [0.0, 0.2, 1.0]
     with pytest.raises(ValueError):
         (tmp_path / "bad.ply").write_text("nope\n")
         ply.read_point_cloud(str(tmp_path / "bad.ply"))

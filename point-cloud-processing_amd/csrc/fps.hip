@@ -1511,6 +1511,7 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
 // the slot word; the claimer's compare-and-swap -> agent-scope acquire (drops this CU's L1) -> vmcnt -> barrier ->
 // plain loads.  The min-distance and record arrays travel the same way (they are the bulk of a cloud's state and stay
 // in place).
+#define PCP_FPS_WIDE_PTS (64 * 1024)                  // points a wide-shape workgroup holds in whole (64-row) buckets
 #define PCP_FPS_SLICE_STATE_BYTES (73728 + 256)      // per cloud: arg-max xyz 16K | ring 16K | keys 8K | sec 4K | pend 4K | boxes 24K | header
 #define PCP_FPS_SLICE_MAX_B 1024                     // slot-word packing: 10 bits of cloud number beside 21 bits of run time
 #define PCP_FPS_SLICE_MAX_SLOTS 256
@@ -1627,10 +1628,17 @@ __device__ __forceinline__ void
 fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                 float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
-                int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
-                const int lead)
+                int* __restrict__ overflow, unsigned* __restrict__ ctl_all, const int shape, const int defer_mixed,
+                char* __restrict__ state, const int quantum, const int lead)
 {
-    constexpr int NW = T / 64, NBMAX = T, NCELL = PCP_FPS_NCELL, BS = 64 * BH;
+    // BH = 0: ANY wide shape, chosen per cloud by its size (whole, halved or quartered buckets) - the launch for batches
+    // whose clouds fall into more than one size range.  Launches on one stream run one after the other, so three launches
+    // that each serve a part of such a batch cost the SUM of their times with most of the chip idle in each (300 ray-cast
+    // tabletop frames of 64-83 k points, one of them below 65,536: 1.4 ms for that one cloud, then 2.9 ms for the rest).
+    // fps_slice_prep counts the clouds per shape on the device; with more than one shape present the per-shape launches
+    // exit at once and this one runs every cloud, otherwise this one exits and the per-shape launch runs as before.
+    constexpr bool ANY = BH == 0;
+    constexpr int NW = T / 64, NBMAX = T, NCELL = PCP_FPS_NCELL;
     static_assert(T == 1024, "the saved state is laid out for 1,024 threads: one bucket, one ring entry per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cellcnt = (int*)smem;
@@ -1645,7 +1653,17 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (ctl[PCP_FPS_SLICE_MAX_SLOTS] == 0u) return;              // no cloud of the batch is this shape's (fps_slice_prep)
+    unsigned* ctl = ctl_all + (size_t)shape * PCP_FPS_SLICE_CTL_WORDS;       // this launch's waiting slots (ANY: those of shape 0)
+    {
+        const unsigned n0 = ctl_all[PCP_FPS_SLICE_MAX_SLOTS], n1 = ctl_all[PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS],
+                       n2 = ctl_all[2 * PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS];
+        const bool mixed = ((n0 != 0u) + (n1 != 0u) + (n2 != 0u)) > 1;
+        if (ANY) { if (!mixed) return; }                         // one shape (or none): the per-shape launch runs it
+        else {
+            if (defer_mixed && mixed) return;                    // the ANY launch of this call runs every cloud
+            if (ctl[PCP_FPS_SLICE_MAX_SLOTS] == 0u) return;      // no cloud of the batch is this shape's (fps_slice_prep)
+        }
+    }
     fps_gu32* slot = (fps_gu32*)ctl;
     const int G = (int)gridDim.x;                                // workgroup i starts cloud i; the host keeps G <= B
     const int E = B - G;                                         // extra clouds, E <= min(G, slots): they start in the waiting slots
@@ -1654,6 +1672,7 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
     const int grp = E_l > 0 ? label + 8 * (((int)blockIdx.x >> 3) % E_l) : -1;
 
     int cur = -1, kd = 0, kn = 0, M = 0, NB = 0;
+    int bh = ANY ? 1 : BH;                                       // 64-row parts per bucket of the current cloud (wave-uniform)
     unsigned long long run_t = 0ull;                             // 10 ns ticks this workgroup's cloud has been worked on, here or elsewhere
     unsigned long long key = 0ull;
     float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};
@@ -1737,6 +1756,8 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
                     S = pts4 + base;
                     D = md + base;
                     fps_sort_points<T>(P, M, S, D, cellcnt, red, tid, lane, wave);
+                    if (ANY) bh = M > 2 * PCP_FPS_WIDE_PTS ? 4 : (M > PCP_FPS_WIDE_PTS ? 2 : 1);
+                    const int BS = 64 * bh;
                     NB = (M + BS - 1) / BS;
                     const int j = lane * NW + wave;
                     const int r0 = min(j, NB - 1) * BS;
@@ -1779,7 +1800,8 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
                 __syncthreads();
                 M = (int)Mll;
                 kn = K < M ? K : M;
-                NB = (M + BS - 1) / BS;
+                if (ANY) bh = M > 2 * PCP_FPS_WIDE_PTS ? 4 : (M > PCP_FPS_WIDE_PTS ? 2 : 1);
+                NB = (M + 64 * bh - 1) / (64 * bh);
                 S = pts4 + base;
                 D = md + base;
                 const char* sb = state + (size_t)cur * PCP_FPS_SLICE_STATE_BYTES;
@@ -1810,8 +1832,20 @@ fps_sliced_body(const float* __restrict__ xyz, const long long* __restrict__ off
             const unsigned long long t_in = wall_clock64();
             // (inlined: as a real call the rounds took their pointers as generic ones — flat loads and stores, which also count
             //  against the LDS wait in front of every barrier — and ran 6 % slower)
-            fps_multipick_rounds<T, MODE, BH, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
-                                                          sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+            if constexpr (ANY) {
+                if (bh == 1)
+                    fps_multipick_rounds<T, MODE, 1, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+                                                                  sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+                else if (bh == 2)
+                    fps_multipick_rounds<T, MODE, 2, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+                                                                  sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+                else
+                    fps_multipick_rounds<T, MODE, 4, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+                                                                  sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+            } else {
+                fps_multipick_rounds<T, MODE, BH, true, true, PCP_FPS_MAXP>(kd, kn, t_in + (unsigned long long)quantum, kn, M, NB, S, D, pkey, pxyz, bxyz,
+                                                              sel, okf, ring, irow, orow, tid, lane, wave, key, blo, bhi, cy);
+            }
         }
         run_t += wall_clock64() - t_top;
         if (kd >= kn) {
@@ -1827,11 +1861,11 @@ __global__ void __launch_bounds__(T)
 fps_bucket_sliced(const float* __restrict__ xyz, const long long* __restrict__ offsets, const int B, const int K,
                   long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                   float* __restrict__ md, const int m_lo, const int m_hi, const long long total_pts, const int m_cap,
-                  int* __restrict__ overflow, unsigned* __restrict__ ctl, char* __restrict__ state, const int quantum,
-                  const int lead)
+                  int* __restrict__ overflow, unsigned* __restrict__ ctl_all, const int shape, const int defer_mixed,
+                  char* __restrict__ state, const int quantum, const int lead)
 {
-    fps_sliced_body<T, MODE, BH>(xyz, offsets, B, K, idx, out_xyz, pts4, md, m_lo, m_hi, total_pts, m_cap, overflow, ctl, state,
-                                 quantum, lead);
+    fps_sliced_body<T, MODE, BH>(xyz, offsets, B, K, idx, out_xyz, pts4, md, m_lo, m_hi, total_pts, m_cap, overflow, ctl_all, shape,
+                                 defer_mixed, state, quantum, lead);
 }
 
 // (Measured and dropped: the same body held to 64 VGPRs / 80 SGPRs with TWO resident workgroups per CU, for batches of a
@@ -1897,6 +1931,7 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int lazy;
     int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, 2 = always and with deferred updates, -1 = never
     int slice;                   // quantum-sliced launch: 0 = by batch size, 1 = always (tests), -1 = never
+    int any_shape;               // this call ends its sliced launches with the ANY-shape one: the per-shape ones leave mixed batches to it
     unsigned* slice_ctl;         // [3 wide shapes][PCP_FPS_SLICE_CTL_WORDS slot words], or NULL: the workspace has no room
     char* slice_state;           // [B][PCP_FPS_SLICE_STATE_BYTES]
     hipStream_t st;
@@ -1980,9 +2015,9 @@ static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
     const size_t lds = std::max(fps_bucket_lds_bytes<T, 1>(), (size_t)96 * 1024);
     auto kern = fps_bucket_sliced<T, MODE, BH>;
     PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    unsigned* ctl = c.slice_ctl + (size_t)shape * PCP_FPS_SLICE_CTL_WORDS;        // zeroed by fps_batched_impl, all three shapes at once
+    // (the slot words of all three shapes are zeroed by fps_slice_prep; the ANY-shape launch, BH = 0, waits in shape 0's)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, c.st, c.xyz, c.offsets, c.B, c.K, c.idx, c.out_xyz, c.pts4, c.md,
-                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, ctl, c.slice_state, quantum * 100, lead);
+                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, c.slice_ctl, shape, c.any_shape, c.slice_state, quantum * 100, lead);
     return pcp_launch_status();
 }
 
@@ -2029,6 +2064,9 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     return pcp_launch_status();
 }
 
+#ifndef PCP_FPS_ANY_SHAPE
+#define PCP_FPS_ANY_SHAPE 1      // 0: no ANY-shape sliced launch (tuning builds): mixed batches run shape after shape
+#endif
 #ifndef PCP_FPS_SHAPE
 #define PCP_FPS_SHAPE 0          // 0: wide for small clouds + deep for large; 2: deep only (tuning builds)
 #endif
@@ -2052,6 +2090,10 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     // the top of the size range the launches below cover: a cloud beyond it (the caller understated max_pts) is
     // answered with an all -1 row and the overflow flag by the last launch, never skipped
     c.m_cap = max_pts <= W ? W : (max_pts <= 2 * W ? 2 * W : (max_pts <= split_max ? split_max : 0x7fffffff));
+    // A batch whose clouds fall into more than one wide size range: when all the wide shapes of this call go as sliced
+    // launches, an ANY-shape sliced launch follows them and takes such a batch whole (the per-shape ones then exit at once).
+    c.any_shape = (PCP_FPS_ANY_SHAPE && PCP_FPS_SPLIT4 && c.slice_ctl && c.mp >= 0 && max_pts > W &&
+                   fps_slice_wanted(c.B, c.K, c.slice, W) && (c.slice > 0 || c.B > fps_cu_count())) ? 1 : 0;
     if (c.slice_ctl) {           // every waiting slot of the three sliced shapes: "extra cloud, not started"; clouds per shape
         hipLaunchKernelGGL(fps_slice_prep, dim3(1), dim3(256), 0, c.st, c.offsets, c.B, c.total_pts, c.m_cap, c.slice_ctl);
         if (pcp_launch_status() != PCP_OK) return PCP_ERR_LAUNCH;
@@ -2060,9 +2102,12 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     if (rc != PCP_OK || max_pts <= W) return rc;
     // up to 131,072 / 262,144 points: the same shape with buckets of two / four 64-row parts, streamed side by side
     rc = launch_bucket_as<1024, 1, false, MODE, 2>(c, W + 1, 2 * W);
-    if (rc != PCP_OK || max_pts <= 2 * W) return rc;
+    if (rc != PCP_OK) return rc;
+    if (max_pts <= 2 * W) return c.any_shape ? launch_sliced<MODE, 0>(c, 0, 2 * W, 0) : rc;
     if (PCP_FPS_SPLIT4) {
         rc = launch_bucket_as<1024, 1, false, MODE, 4>(c, 2 * W + 1, 4 * W);
+        if (rc != PCP_OK) return rc;
+        if (c.any_shape) rc = launch_sliced<MODE, 0>(c, 0, 4 * W, 0);
         if (rc != PCP_OK || max_pts <= 4 * W) return rc;
     }
     // larger clouds: a batch that leaves CUs free (one workgroup per CU is enough) gets 1024 threads per cloud —
@@ -2117,7 +2162,7 @@ static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int
     c.xyz = xyz; c.offsets = (const long long*)offsets; c.B = B; c.K = K; c.idx = (long long*)idx; c.out_xyz = out_xyz;
     c.pts4 = (float4*)ws;
     c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
-    c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow;
+    c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow; c.any_shape = 0;
     c.lazy = (algo == 3 || algo == 8) ? 1 : ((algo == 4 || algo == 7) ? -1 : 0);
     c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 9 ? 2 : (algo == 6 ? -1 : 0));
     c.slice = slice ? fps_slice_mode(algo) : -1;

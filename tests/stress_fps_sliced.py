@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak for the quantum-sliced FPS launches (run by hand on the MI355X; tests/test_gpu_soak_slice.py runs a slice):
 batches of 257-336 clouds (the sizes pcp_fps_batched slices by itself) and forced slicing (algo 10) on smaller ones,
-random K and distance mode, every launch repeated while a second stream keeps some CUs busy with unrelated work (uneven
+random K and distance mode, cloud sizes within one launch shape or across two or three of them (one any-shape launch), every launch repeated while a second stream keeps some CUs busy with unrelated work (uneven
 load moves the quantum ends and with them who hands which cloud to whom).  Every cloud of every repeat must equal the
 resident launch's result (algo 5), which is itself checked against the C oracle on a sample of clouds."""
 import argparse, os, sys, time
@@ -28,7 +28,8 @@ def main(argv=None):
         B = int(rng.integers(257, 337)) if auto else int(rng.integers(2, 120))
         if auto and rng.random() < 0.15:
             B = int(rng.integers(513, 625))                             # two launches over the halves of the batch
-        top = int(rng.choice([6000, 30000, 65536, 100000])) if not auto else int(rng.choice([8000, 30000, 65536]))
+        # tops beyond 65,536 make mixed-size batches: those go as ONE any-shape sliced launch
+        top = int(rng.choice([6000, 30000, 65536, 100000, 150000])) if not auto else int(rng.choice([8000, 30000, 65536, 90000, 140000]))
         sizes = rng.integers(2048, top + 1, B)
         sizes[rng.integers(0, B)] = top
         if rng.random() < 0.3:

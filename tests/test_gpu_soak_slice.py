@@ -109,6 +109,45 @@ def test_fps_quantum_sliced_launch_equals_the_sequential_picks():
                 np.testing.assert_array_equal(xyz[b].cpu().numpy(), rx)
 
 
+def test_fps_mixed_size_episode_goes_as_one_any_shape_sliced_launch():
+    """257-336 clouds per call whose sizes straddle 65,536 (and 131,072) points, algo 0: fps_slice_prep finds more than one wide
+    shape in the batch, the per-shape sliced launches exit at once and the ANY-shape launch runs every cloud with the bucket
+    split its size asks for — equal to the resident launches (algo 5, shape after shape) on every cloud and to the oracle on a
+    sample; a batch of one shape only still goes through its own per-shape launch (same check)."""
+    import stress_fps
+    rng = np.random.default_rng(300)
+    for case, (B, K, dm) in enumerate(((300, 300, 1), (272, 257, 0), (300, 256, 1))):
+        if case == 0:
+            sizes = rng.integers(60000, 72000, B)                  # whole and halved buckets, about half each
+            sizes[7], sizes[150], sizes[299] = 0, 140000, 65536
+        elif case == 1:
+            sizes = rng.integers(20000, 30000, B)
+            sizes[5], sizes[100], sizes[271] = 70000, 135000, 65537   # three shapes, two of them with one cloud only
+        else:
+            sizes = rng.integers(66000, 70000, B)                  # one shape (halved buckets) only
+        base = stress_fps.make_cloud(rng, int(sizes.max()))
+        off = np.zeros(B + 1, np.int64); off[1:] = np.cumsum(sizes)
+        pts = np.concatenate([base[rng.permutation(len(base))[:m]] + np.float32(0.001 * (b % 7)) for b, m in enumerate(sizes)])
+        cat, offd = torch.from_numpy(pts).cuda(), torch.from_numpy(off).cuda()
+        mx = int(sizes.max())
+        ref = ops.Fps(B, len(pts), mx, K, "cuda", dm, 5)
+        rx, ri = ref.run(cat, offd)
+        got = ops.Fps(B, len(pts), mx, K, "cuda", dm, 0)
+        got.idx.fill_(-7)
+        for rep in range(2):                                       # the second call finds the first one's slot words and state
+            gx, gi = got.run(cat, offd)
+            torch.cuda.synchronize()
+            assert int(got.overflow.item()) == 0
+            assert torch.equal(gi, ri) and torch.equal(gx.view(torch.int32), rx.view(torch.int32)), (case, rep)
+        for b in (0, 5, 7, 100, 150, B - 1):
+            if sizes[b] == 0:
+                assert (gi[b] == -1).all()
+                continue
+            ox, oi = cbind.fps(pts[off[b]:off[b + 1]], K, dm)
+            np.testing.assert_array_equal(gi[b].cpu().numpy(), oi, err_msg=f"case {case} cloud {b} M={sizes[b]}")
+            np.testing.assert_array_equal(gx[b].cpu().numpy(), ox)
+
+
 def test_fps_batch_of_a_little_more_than_two_clouds_per_cu_goes_as_two_sliced_launches():
     """513-624 clouds per call (algo 0): two launches over the halves of the batch, each quantum-sliced — equal to the
     resident launch (algo 5) on every cloud and to the oracle on a sample, with and without out_xyz rows of the second half

@@ -351,6 +351,9 @@ __device__ __forceinline__ float rl(float v, int lane)
                                  // picks): bit-exact, but every round pays for eight samples' worth of registers and unrolled code (108
                                  // scalar spills in the sliced kernel) - 300 clouds 2.54 instead of 2.40 ms, 1 cloud 1.51 / 1.48, 256: 2.01 / 1.94
 #endif
+// control words of the quantum-sliced launches (below), also read by the resident multi-pick kernel
+#define PCP_FPS_SLICE_MAX_SLOTS 256
+#define PCP_FPS_SLICE_CTL_WORDS (PCP_FPS_SLICE_MAX_SLOTS + 64)    // per wide shape: the waiting slots, then the number of clouds the shape serves
 #define PCP_BX(j, NW, PER_WAVE) (((j) % (NW)) * (PER_WAVE) + (j) / (NW))
 #define PCP_FPS_RED 128          // floats of LDS scratch: bounding-box partials (6 per wave, <= 16 waves), scan scratch
 #define PCP_FPS_CELL_BITS 12
@@ -1452,7 +1455,7 @@ __global__ void __launch_bounds__(T, 2048 / T) __attribute__((amdgpu_num_sgpr(80
 fps_bucket_wide(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                 float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
-                int* __restrict__ overflow)
+                int* __restrict__ overflow, const unsigned* __restrict__ mixed_ctl)
 {
     fps_bucket_body<T, CPL, false, MODE, BH>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts,
                                              m_cap, overflow);
@@ -1467,8 +1470,15 @@ __global__ void __launch_bounds__(T)
 fps_bucket_wide_mp(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                    long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                    float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
-                   int* __restrict__ overflow)
+                   int* __restrict__ overflow, const unsigned* __restrict__ mixed_ctl)
 {
+    // A batch with clouds in more than one wide size range (counted by fps_slice_prep): the call's any-shape launch runs
+    // it whole, see fps_sliced_body - one launch after the other would cost the sum of their times.
+    if (mixed_ctl) {
+        const unsigned n0 = mixed_ctl[PCP_FPS_SLICE_MAX_SLOTS], n1 = mixed_ctl[PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS],
+                       n2 = mixed_ctl[2 * PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS];
+        if (((n0 != 0u) + (n1 != 0u) + (n2 != 0u)) > 1) return;
+    }
     fps_bucket_body<T, CPL, false, MODE, BH, true, DEFER, PCP_FPS_MAXP>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
                                                                         total_pts, m_cap, overflow);
 }
@@ -1481,7 +1491,7 @@ __global__ void __launch_bounds__(T, 8) __attribute__((amdgpu_num_sgpr(80), amdg
 fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                     long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                     float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
-                    int* __restrict__ overflow)
+                    int* __restrict__ overflow, const unsigned* __restrict__ mixed_ctl)
 {
     fps_bucket_body<T, CPL, false, MODE, BH, true, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
                                                          total_pts, m_cap, overflow);
@@ -1514,7 +1524,6 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
 #define PCP_FPS_WIDE_PTS (64 * 1024)                  // points a wide-shape workgroup holds in whole (64-row) buckets
 #define PCP_FPS_SLICE_STATE_BYTES (73728 + 256)      // per cloud: arg-max xyz 16K | ring 16K | keys 8K | sec 4K | pend 4K | boxes 24K | header
 #define PCP_FPS_SLICE_MAX_B 1024                     // slot-word packing: 10 bits of cloud number beside 21 bits of run time
-#define PCP_FPS_SLICE_MAX_SLOTS 256
 typedef __attribute__((address_space(1))) unsigned int fps_gu32;
 // slot word j: 0 = extra cloud G + j, not started yet; 1 = empty; else 1<<31 | microseconds the cloud has run << 10 | cloud
 #define FPS_SLOT_EMPTY 1u
@@ -1598,7 +1607,6 @@ __device__ __forceinline__ int fps_slice_choose(fps_gu32* slot, const int G, con
     return -1;
 }
 
-#define PCP_FPS_SLICE_CTL_WORDS (PCP_FPS_SLICE_MAX_SLOTS + 64)    // per sliced shape: the waiting slots, then the number of clouds the shape serves
 
 // Ahead of a call's sliced launches: every waiting slot of the three wide shapes to "extra cloud, not started", and how
 // many clouds each shape has to touch at all — a launch for a size range no cloud of the batch falls into (the host only
@@ -1878,7 +1886,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_num_sgpr(80)))
 fps_bucket_deep(const float* __restrict__ xyz, const long long* __restrict__ offsets, int K,
                 long long* __restrict__ idx, float* __restrict__ out_xyz, float4* __restrict__ pts4,
                 float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
-                int* __restrict__ overflow)
+                int* __restrict__ overflow, const unsigned* __restrict__ mixed_ctl)
 {
     fps_bucket_body<T, CPL, true, MODE>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k, total_pts, m_cap,
                                         overflow);
@@ -1898,6 +1906,7 @@ static size_t fps_base_workspace_bytes(int64_t total_pts)
     return pcp_align256((size_t)total_pts * 16) + pcp_align256((size_t)total_pts * 4) + 256;
 }
 static int fps_slice_mode(int algo) { return algo == 10 ? 1 : ((algo == 0 || algo == 2) ? 0 : -1); }
+static bool fps_mixed_ctl_wanted(int B, int slice, int64_t max_pts);
 static bool fps_slice_wanted(int B, int K, int slice, int64_t max_pts);
 static bool fps_split_wanted(int B, int K, int slice, int64_t max_pts);
 static size_t fps_slice_bytes(int B);
@@ -1909,6 +1918,7 @@ extern "C" size_t pcp_fps_workspace_bytes(int B, int64_t total_pts, int64_t max_
     // quantum-sliced launches (batches of a little more than one cloud per CU) park the round state of a waiting cloud
     if (fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes(B);
     else if (fps_split_wanted(B, K, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes((B + 1) / 2);
+    else if (fps_mixed_ctl_wanted(B, fps_slice_mode(algo), max_pts)) n += fps_slice_bytes(0);   // the control words only
     return n;
 }
 
@@ -1931,12 +1941,16 @@ struct FpsCall {                 // everything a launch needs besides its shape
     int lazy;
     int mp;                      // multi-pick rounds: 0 = by batch size, 1 = always, 2 = always and with deferred updates, -1 = never
     int slice;                   // quantum-sliced launch: 0 = by batch size, 1 = always (tests), -1 = never
-    int any_shape;               // this call ends its sliced launches with the ANY-shape one: the per-shape ones leave mixed batches to it
+    int any_shape;               // this call ends its wide launches with the ANY-shape one: the per-shape ones leave mixed batches to it
+    int ctl_only;                // the workspace holds the control words but no room for parked state (resident-size batches)
     unsigned* slice_ctl;         // [3 wide shapes][PCP_FPS_SLICE_CTL_WORDS slot words], or NULL: the workspace has no room
     char* slice_state;           // [B][PCP_FPS_SLICE_STATE_BYTES]
     hipStream_t st;
 };
 
+#ifndef PCP_FPS_ANY_SHAPE
+#define PCP_FPS_ANY_SHAPE 1      // 0: no ANY-shape sliced launch (tuning builds): mixed batches run shape after shape
+#endif
 #ifndef PCP_FPS_SLICE_MIN_B
 #define PCP_FPS_SLICE_MIN_B 257          // sliced launches for batches of more clouds than CUs ...
 #endif
@@ -1985,6 +1999,14 @@ static bool fps_split_wanted(int B, int K, int slice, int64_t max_pts)
            fps_slice_wanted((B + 1) / 2, K, 0, max_pts) && !fps_slice_wanted(B, K, 0, max_pts);
 }
 
+// A resident-size batch (one workgroup per CU at most) whose size bound allows more than one wide shape: the workspace
+// carries the control words, fps_slice_prep counts the clouds per shape, and a batch that does mix shapes runs as one
+// any-shape launch (nobody waits, so no parked state) instead of shape after shape.
+static bool fps_mixed_ctl_wanted(int B, int slice, int64_t max_pts)
+{
+    return PCP_FPS_ANY_SHAPE && slice == 0 && B >= 2 && B < PCP_FPS_SLICE_MIN_B && max_pts > 65536;
+}
+
 static size_t fps_slice_bytes(int B)
 {
     return pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) + (size_t)B * PCP_FPS_SLICE_STATE_BYTES;
@@ -2017,7 +2039,7 @@ static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
     PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // (the slot words of all three shapes are zeroed by fps_slice_prep; the ANY-shape launch, BH = 0, waits in shape 0's)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, c.st, c.xyz, c.offsets, c.B, c.K, c.idx, c.out_xyz, c.pts4, c.md,
-                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, c.slice_ctl, shape, c.any_shape, c.slice_state, quantum * 100, lead);
+                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, c.slice_ctl, shape, c.any_shape == 1 ? 1 : 0, c.slice_state, quantum * 100, lead);
     return pcp_launch_status();
 }
 
@@ -2035,7 +2057,7 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     }
     constexpr size_t lds = fps_bucket_lds_bytes<T, CPL>();
     void (*kern)(const float*, const long long*, int, long long*, float*, float4*, float*, int, int, int, long long,
-                 int, int*);
+                 int, int*, const unsigned*);
     if constexpr (MULTI) kern = fps_bucket_deep<T, CPL, MODE>;
     else {
         kern = fps_bucket_wide<T, CPL, MODE, BH>;
@@ -2060,13 +2082,11 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
     if (lds > 48 * 1024)         // the only process-wide state the library touches: a per-kernel attribute, same value every time
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(c.B), dim3(T), lds, c.st, c.xyz, c.offsets, c.K, c.idx, c.out_xyz, c.pts4, c.md,
-                       m_lo, m_hi, lazy_k, c.total_pts, c.m_cap, c.overflow);
+                       m_lo, m_hi, lazy_k, c.total_pts, c.m_cap, c.overflow,
+                       (const unsigned*)(c.any_shape == 2 && !MULTI && CPL == 1 ? c.slice_ctl : nullptr));
     return pcp_launch_status();
 }
 
-#ifndef PCP_FPS_ANY_SHAPE
-#define PCP_FPS_ANY_SHAPE 1      // 0: no ANY-shape sliced launch (tuning builds): mixed batches run shape after shape
-#endif
 #ifndef PCP_FPS_SHAPE
 #define PCP_FPS_SHAPE 0          // 0: wide for small clouds + deep for large; 2: deep only (tuning builds)
 #endif
@@ -2092,8 +2112,13 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     c.m_cap = max_pts <= W ? W : (max_pts <= 2 * W ? 2 * W : (max_pts <= split_max ? split_max : 0x7fffffff));
     // A batch whose clouds fall into more than one wide size range: when all the wide shapes of this call go as sliced
     // launches, an ANY-shape sliced launch follows them and takes such a batch whole (the per-shape ones then exit at once).
-    c.any_shape = (PCP_FPS_ANY_SHAPE && PCP_FPS_SPLIT4 && c.slice_ctl && c.mp >= 0 && max_pts > W &&
-                   fps_slice_wanted(c.B, c.K, c.slice, W) && (c.slice > 0 || c.B > fps_cu_count())) ? 1 : 0;
+    // (1: the per-shape launches are sliced ones; 2: they are resident multi-pick launches of at most one workgroup per CU,
+    //  and the any-shape launch has a workgroup for every cloud - nobody waits, no state is parked)
+    c.any_shape = 0;
+    if (PCP_FPS_ANY_SHAPE && PCP_FPS_SPLIT4 && c.slice_ctl && c.mp >= 0 && max_pts > W) {
+        if (fps_slice_wanted(c.B, c.K, c.slice, W) && (c.slice > 0 || c.B > fps_cu_count())) c.any_shape = 1;
+        else if (c.ctl_only && c.slice == 0 && c.mp == 0 && c.B >= 2 && c.B <= fps_cu_count() && c.B <= PCP_FPS_MP_MAX_B) c.any_shape = 2;
+    }
     if (c.slice_ctl) {           // every waiting slot of the three sliced shapes: "extra cloud, not started"; clouds per shape
         hipLaunchKernelGGL(fps_slice_prep, dim3(1), dim3(256), 0, c.st, c.offsets, c.B, c.total_pts, c.m_cap, c.slice_ctl);
         if (pcp_launch_status() != PCP_OK) return PCP_ERR_LAUNCH;
@@ -2119,7 +2144,7 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
 
 static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
                             int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
-                            void* ws, size_t base_bytes, bool slice, hipStream_t st);
+                            void* ws, size_t base_bytes, int slice_kind, hipStream_t st);
 
 // shared by pcp_fps_batched and its no-allocation twin: argument checks, workspace carve-up, launches
 static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
@@ -2139,35 +2164,41 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
         if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + fps_slice_bytes(h)) return PCP_ERR_WORKSPACE;
         if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
         int rc = fps_launch_batch(xyz, offsets, h, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws, base_bytes,
-                                  true, st);
+                                  1, st);
         if (rc != PCP_OK) return rc;
         return fps_launch_batch(xyz, offsets + h, B - h, total_pts, max_pts, K, dist_mode, algo, idx + (size_t)h * K,
                                 out_xyz ? out_xyz + (size_t)h * K * 3 : nullptr, overflow, ws, base_bytes,
-                                fps_slice_wanted(B - h, K, 0, max_pts), st);
+                                fps_slice_wanted(B - h, K, 0, max_pts) ? 1 : 0, st);
     }
     const bool slice = allow_slice && fps_slice_wanted(B, K, fps_slice_mode(algo), max_pts);
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < base_bytes + (slice ? fps_slice_bytes(B) : 0))
         return PCP_ERR_WORKSPACE;
+    // control words only (mixed-size batches of resident size): used when the workspace has them - pcp_fps_workspace_bytes
+    // asks for them -, done without otherwise (shape after shape: slower on a mixed batch, same picks)
+    const bool ctl_only = allow_slice && !slice && fps_mixed_ctl_wanted(B, fps_slice_mode(algo), max_pts) &&
+                          fps_pick_algo(algo, max_pts) == 2 && ws_bytes >= base_bytes + fps_slice_bytes(0);
     if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || K == 0) return PCP_OK;
-    return fps_launch_batch(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws, base_bytes, slice, st);
+    return fps_launch_batch(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws, base_bytes,
+                            slice ? 1 : (ctl_only ? 2 : 0), st);
 }
 
 // the launches for clouds [0, B) of `offsets` (arguments checked, overflow flag cleared by the caller)
 static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
                             int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
-                            void* ws, size_t base_bytes, bool slice, hipStream_t st)
+                            void* ws, size_t base_bytes, int slice_kind, hipStream_t st)
 {
     FpsCall c;
     c.xyz = xyz; c.offsets = (const long long*)offsets; c.B = B; c.K = K; c.idx = (long long*)idx; c.out_xyz = out_xyz;
     c.pts4 = (float4*)ws;
     c.md = (float*)((char*)ws + pcp_align256((size_t)total_pts * 16));
-    c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow; c.any_shape = 0;
+    c.total_pts = total_pts; c.m_cap = 0x7fffffff; c.overflow = overflow; c.any_shape = 0; c.ctl_only = 0;
     c.lazy = (algo == 3 || algo == 8) ? 1 : ((algo == 4 || algo == 7) ? -1 : 0);
     c.mp = (algo == 5 || algo == 7 || algo == 8) ? 1 : (algo == 9 ? 2 : (algo == 6 ? -1 : 0));
-    c.slice = slice ? fps_slice_mode(algo) : -1;
-    c.slice_ctl = slice ? (unsigned*)((char*)ws + base_bytes) : nullptr;
-    c.slice_state = slice ? (char*)ws + base_bytes + pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
+    c.slice = slice_kind ? fps_slice_mode(algo) : -1;
+    c.slice_ctl = slice_kind ? (unsigned*)((char*)ws + base_bytes) : nullptr;
+    c.slice_state = slice_kind == 1 ? (char*)ws + base_bytes + pcp_align256((size_t)3 * PCP_FPS_SLICE_CTL_WORDS * 4) : nullptr;
+    c.ctl_only = slice_kind == 2 ? 1 : 0;
     c.st = st;
     if (fps_pick_algo(algo, max_pts) == 2)
         return dist_mode == 0 ? launch_bucket<0>(c, max_pts) : launch_bucket<1>(c, max_pts);

@@ -59,7 +59,7 @@ def test_argument_validation_without_device():
 def test_fps_workspace_grows_only_where_launches_are_sliced():
     """pcp_fps_workspace_bytes: 20 B per point everywhere; plus the parked round state (72.25 KB per cloud + slot words) only
     for the batches pcp_fps_batched runs as quantum-sliced launches — 257-336 clouds (to 512 when max_pts promises clouds of
-    more than 131,072 points) at K >= 256 with algo 0 / 2, or any batch of 2-960 clouds with algo 10 (pcp.h)."""
+    more than 131,072 points) at K >= 256 with algo 0 / 2, or any batch of 2-960 clouds with algo 10 (pcp.h); a few KB of control words for resident-size batches that may mix launch shapes."""
     L = _ffi.load_library()
     base = L.pcp_fps_workspace_bytes(1, 10 ** 6, 65536, 1024, 5)
     assert base >= 20 * 10 ** 6
@@ -78,6 +78,16 @@ def test_fps_workspace_grows_only_where_launches_are_sliced():
             assert B * state <= e <= B * state + 8192, (B, K, algo, e)
         else:
             assert e == 0, (B, K, algo, e)
+    # resident-size batches (2-256 clouds, algo 0 / 2) whose size bound allows more than one wide launch shape: the control words
+    # only (a mixed-size batch then runs as ONE any-shape launch; nobody waits, so no parked state)
+    for B, K, algo, max_pts, ctl in [(64, 1024, 0, 65537, True), (256, 2500, 2, 307200, True), (2, 16, 0, 131072, True),
+                                     (1, 1024, 0, 307200, False), (64, 1024, 0, 65536, False), (64, 1024, 5, 307200, False),
+                                     (64, 1024, 10, 307200, None)]:
+        e = extra(B, K, algo, max_pts)
+        if ctl is None:
+            assert e >= B * state                          # forced slicing: slots and state, as above
+        else:
+            assert (0 < e <= 8192) if ctl else e == 0, (B, K, algo, max_pts, e)
     # 513-624 clouds go as two launches over the halves of the batch, each sliced: room for the larger half
     for B, K, algo, max_pts, half in [(513, 1024, 0, 65536, 257), (600, 1024, 2, 65536, 300), (624, 2500, 0, 65536, 312),
                                       (600, 1024, 0, 4 * 65536, 300), (625, 1024, 0, 65536, 0), (600, 1024, 5, 65536, 0),

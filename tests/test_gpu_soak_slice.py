@@ -148,6 +148,45 @@ def test_fps_mixed_size_episode_goes_as_one_any_shape_sliced_launch():
             np.testing.assert_array_equal(gx[b].cpu().numpy(), ox)
 
 
+def test_fps_mixed_size_batches_of_resident_size_go_as_one_any_shape_launch():
+    """2-256 clouds per call (algo 0, the 64-cloud chunks of the stage-2 mirror) with sizes on both sides of 65,536 / 131,072
+    points: one any-shape launch with a workgroup per cloud instead of one resident launch per shape — every cloud against the
+    oracle; a workspace without the control words (an older caller's size) still gives the same picks."""
+    import stress_fps
+    from pcp import _ffi
+    rng = np.random.default_rng(64)
+    for case, sizes in enumerate(([61000, 70000, 64000, 66000, 131072, 140000, 5, 0, 65536, 65537, 3000, 90000],
+                                  [70000, 60000], [20000] * 3 + [200000], [66000] * 5)):
+        K, dm = (300, 1024, 257, 500)[case], case & 1
+        clouds = [stress_fps.make_cloud(rng, m) if m else np.zeros((0, 3), np.float32) for m in sizes]
+        off = np.zeros(len(sizes) + 1, np.int64); off[1:] = np.cumsum(sizes)
+        cat, offd = torch.from_numpy(np.concatenate(clouds)).cuda(), torch.from_numpy(off).cuda()
+        plan = ops.Fps(len(sizes), cat.shape[0], max(sizes), K, "cuda", dm, 0)
+        base = ops.Fps(len(sizes), cat.shape[0], max(sizes), K, "cuda", dm, 5).ws_bytes
+        assert 0 < plan.ws_bytes - base <= 8192                     # the control words
+        ref = [cbind.fps(c, K, dm) if len(c) else None for c in clouds]
+        for rep in range(2):
+            plan.idx.fill_(-7)
+            xyz, idx = plan.run(cat, offd)
+            torch.cuda.synchronize()
+            assert int(plan.overflow.item()) == 0
+            for b, c in enumerate(clouds):
+                if ref[b] is None:
+                    assert (idx[b] == -1).all()
+                    continue
+                np.testing.assert_array_equal(idx[b].cpu().numpy(), ref[b][1], err_msg=f"case {case} rep {rep} cloud {b} M={sizes[b]}")
+                np.testing.assert_array_equal(xyz[b].cpu().numpy(), ref[b][0])
+        # the same call through the C ABI with the smaller workspace of a caller that did not ask again: shape after shape
+        L = _ffi.load_library()
+        ws = torch.empty(base + 256, dtype=torch.uint8, device="cuda")
+        wp = (ws.data_ptr() + 255) & ~255
+        idx2 = torch.full((len(sizes), K), -7, dtype=torch.int64, device="cuda")
+        rc = L.pcp_fps_batched(cat.data_ptr(), offd.data_ptr(), len(sizes), cat.shape[0], max(sizes), K, dm, 0, idx2.data_ptr(), None,
+                               None, wp, base, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and torch.equal(idx2, idx)
+
+
 def test_fps_batch_of_a_little_more_than_two_clouds_per_cu_goes_as_two_sliced_launches():
     """513-624 clouds per call (algo 0): two launches over the halves of the batch, each quantum-sliced — equal to the
     resident launch (algo 5) on every cloud and to the oracle on a sample, with and without out_xyz rows of the second half

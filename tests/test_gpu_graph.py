@@ -95,8 +95,10 @@ def test_static_entry_point_records_into_a_hip_graph():
 def test_every_fps_launch_shape_records_into_a_hip_graph(algo):
     """max_pts > 262,144 makes pcp_fps_batched launch all four bucket shapes (wide, halved, quartered buckets, deep — the
     deep one raises its dynamic-LDS limit with hipFuncSetAttribute on every launch): record them, replay on other clouds
-    of the same sizes, compare with the eager call.  algo 10: the three wide shapes as quantum-sliced launches (slot prep
-    kernel, 96 KB of dynamic LDS set under capture, clouds changing workgroups during the replay)."""
+    of the same sizes, compare with the eager call.  The batch mixes the three wide size classes, so since the end of round 3
+    the per-shape launches exit at once and the ANY-shape launch runs those clouds, under capture too (algo 0: a workgroup per
+    cloud; algo 10: as a quantum-sliced launch — slot prep kernel, 96 KB of dynamic LDS set under capture, clouds changing
+    workgroups during the replay)."""
     rng = np.random.default_rng(9)
     sizes = [3000, 70000, 140000, 270000, 64, 60000, 61000, 100000]
     K = 96 if algo == 0 else 700

@@ -262,7 +262,9 @@ int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, int64_t tot
  * overlap on the same GPU (different streams or threads) race — serialise them.  Nothing has to be cleared
  * between calls (a launch rewrites every row it reads).  Quantum-sliced launches (algo 10, or 0 / 2 at 257-336
  * clouds) are not made here — their parked round state would not fit the array — so such a batch runs with two
- * resident workgroups per CU instead, same results.
+ * resident workgroups per CU instead, same results (and one size class after the other when it mixes them); a mixed-size
+ * batch of 2-256 clouds does run as one any-shape launch, as in pcp_fps_batched: its 3.8 KB of control words sit in the
+ * array behind the records and are rewritten by every call.
  * The FIRST call on a device resolves the array's device address (hipGetSymbolAddress, which may also make the
  * runtime load the code object that holds the 32 MiB array): make that call — or pcp_fps_static_prepare(), which does
  * nothing else — once per device OUTSIDE graph capture, as a warm-up; every later call only enqueues kernels.

@@ -2149,8 +2149,11 @@ static int fps_launch_batch(const float* xyz, const int64_t* offsets, int B, int
 // shared by pcp_fps_batched and its no-allocation twin: argument checks, workspace carve-up, launches
 static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int64_t total_pts, int64_t max_pts,
                             int K, int dist_mode, int algo, int64_t* idx, float* out_xyz, int32_t* overflow,
-                            void* ws, size_t ws_bytes, hipStream_t st, bool allow_slice)
+                            void* ws, size_t ws_bytes, hipStream_t st, int slice_allow)
 {
+    // slice_allow 2: quantum-sliced launches and the control words of the any-shape launch; 1: the control words only (the
+    // no-allocation entry point: parked round state would not fit its array); 0: neither
+    const bool allow_slice = slice_allow == 2, allow_ctl = slice_allow >= 1;
     if (B < 0 || K < 0 || total_pts < 0 || max_pts < 0 || !offsets || (dist_mode != 0 && dist_mode != 1) ||
         algo < 0 || algo > 10)
         return PCP_ERR_INVALID_ARG;
@@ -2175,7 +2178,7 @@ static int fps_batched_impl(const float* xyz, const int64_t* offsets, int B, int
         return PCP_ERR_WORKSPACE;
     // control words only (mixed-size batches of resident size): used when the workspace has them - pcp_fps_workspace_bytes
     // asks for them -, done without otherwise (shape after shape: slower on a mixed batch, same picks)
-    const bool ctl_only = allow_slice && !slice && fps_mixed_ctl_wanted(B, fps_slice_mode(algo), max_pts) &&
+    const bool ctl_only = allow_ctl && !slice && fps_mixed_ctl_wanted(B, fps_slice_mode(algo), max_pts) &&
                           fps_pick_algo(algo, max_pts) == 2 && ws_bytes >= base_bytes + fps_slice_bytes(0);
     if (overflow) PCP_FILL_TRY(overflow, 0u, 1, st);
     if (B == 0 || K == 0) return PCP_OK;
@@ -2216,7 +2219,7 @@ extern "C" int pcp_fps_batched(const float* xyz, const int64_t* offsets, int B, 
                                float* out_xyz, int32_t* overflow, void* ws, size_t ws_bytes, void* stream)
 {
     return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
-                            ws_bytes, (hipStream_t)stream, true);
+                            ws_bytes, (hipStream_t)stream, 2);
 }
 
 // ---- no-allocation twin of pcp_fps_batched -----------------------------------------------------------------------
@@ -2275,7 +2278,11 @@ extern "C" int pcp_fps_batched_static(const float* xyz, const int64_t* offsets, 
     if (rc != PCP_OK) return rc;
     // Nothing in the workspace has to start at zero: every launch rewrites the records and min-distances of the rows
     // it reads before it reads them, so the previous call's contents are never observed.
-    // (no quantum-sliced launches here: their parked round state would not fit the array beside the records)
+    // (no quantum-sliced launches here: their parked round state would not fit the array beside the records.  The 3.8 KB of
+    //  control words behind the records do - fps_slice_prep rewrites them in every call -, so a mixed-size batch of 2-256
+    //  clouds still runs as one any-shape launch with a workgroup per cloud, where nothing is parked.)
+    static_assert((size_t)PCP_FPS_STATIC_MAX_PTS * 20 + 1024 + 3 * PCP_FPS_SLICE_CTL_WORDS * 4 + 256 <= PCP_FPS_STATIC_BYTES,
+                  "records, min-distances and the control words fit the static array");
     return fps_batched_impl(xyz, offsets, B, total_pts, max_pts, K, dist_mode, algo, idx, out_xyz, overflow, ws,
-                            fps_base_workspace_bytes(total_pts), (hipStream_t)stream, false);
+                            fps_base_workspace_bytes(total_pts) + fps_slice_bytes(0), (hipStream_t)stream, 1);
 }

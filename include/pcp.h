@@ -226,7 +226,7 @@ int pcp_crop_compact_batched(const double* xyz, const double* rgb, const int64_t
  *                2.83 ms; up to 512 clouds when max_pts is beyond 131,072; 513-624 clouds as two such launches over the
  *                halves of the batch); pcp_fps_workspace_bytes then asks for 72 KB more per cloud (per cloud of the larger
  *                half), where waiting clouds park their round state.  3-9 never launch that way.
- *                A batch of up to 336 clouds (algo 0 / 2) whose sizes fall on both sides of 65,536 or 131,072 points runs as ONE
+ *                A batch of up to 336 clouds (to 512 when max_pts > 131,072; algo 0 / 2) whose sizes fall on both sides of 65,536 or 131,072 points runs as ONE
  *                launch that chooses the bucket split per cloud, instead of one launch per size class after the other; for
  *                2-256 clouds pcp_fps_workspace_bytes adds a few KB of control words for it when max_pts > 65,536 (a
  *                workspace without them is accepted: the size classes then run one after the other, same picks).

@@ -1493,6 +1493,11 @@ fps_bucket_wide_mp2(const float* __restrict__ xyz, const long long* __restrict__
                     float* __restrict__ md, int m_lo, int m_hi, int lazy_k, long long total_pts, int m_cap,
                     int* __restrict__ overflow, const unsigned* __restrict__ mixed_ctl)
 {
+    if (mixed_ctl) {                                             // a mixed-size batch: the call's any-shape launch runs it (see fps_bucket_wide_mp)
+        const unsigned n0 = mixed_ctl[PCP_FPS_SLICE_MAX_SLOTS], n1 = mixed_ctl[PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS],
+                       n2 = mixed_ctl[2 * PCP_FPS_SLICE_CTL_WORDS + PCP_FPS_SLICE_MAX_SLOTS];
+        if (((n0 != 0u) + (n1 != 0u) + (n2 != 0u)) > 1) return;
+    }
     fps_bucket_body<T, CPL, false, MODE, BH, true, true>(xyz, offsets, K, idx, out_xyz, pts4, md, m_lo, m_hi, lazy_k,
                                                          total_pts, m_cap, overflow);
 }
@@ -2039,7 +2044,7 @@ static int launch_sliced(const FpsCall& c, int m_lo, int m_hi, int shape)
     PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // (the slot words of all three shapes are zeroed by fps_slice_prep; the ANY-shape launch, BH = 0, waits in shape 0's)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, c.st, c.xyz, c.offsets, c.B, c.K, c.idx, c.out_xyz, c.pts4, c.md,
-                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, c.slice_ctl, shape, c.any_shape == 1 ? 1 : 0, c.slice_state, quantum * 100, lead);
+                       m_lo, m_hi, c.total_pts, c.m_cap, c.overflow, c.slice_ctl, shape, (c.any_shape == 1 || c.any_shape == 3) ? 1 : 0, c.slice_state, quantum * 100, lead);
     return pcp_launch_status();
 }
 
@@ -2083,7 +2088,7 @@ static int launch_bucket_as(const FpsCall& c, int m_lo, int m_hi)
         PCP_HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(c.B), dim3(T), lds, c.st, c.xyz, c.offsets, c.K, c.idx, c.out_xyz, c.pts4, c.md,
                        m_lo, m_hi, lazy_k, c.total_pts, c.m_cap, c.overflow,
-                       (const unsigned*)(c.any_shape == 2 && !MULTI && CPL == 1 ? c.slice_ctl : nullptr));
+                       (const unsigned*)(c.any_shape >= 2 && !MULTI && CPL == 1 ? c.slice_ctl : nullptr));
     return pcp_launch_status();
 }
 
@@ -2118,6 +2123,12 @@ static int launch_bucket(FpsCall c, int64_t max_pts)
     if (PCP_FPS_ANY_SHAPE && PCP_FPS_SPLIT4 && c.slice_ctl && c.mp >= 0 && max_pts > W) {
         if (fps_slice_wanted(c.B, c.K, c.slice, W) && (c.slice > 0 || c.B > fps_cu_count())) c.any_shape = 1;
         else if (c.ctl_only && c.slice == 0 && c.mp == 0 && c.B >= 2 && c.B <= fps_cu_count() && c.B <= PCP_FPS_MP_MAX_B) c.any_shape = 2;
+        // 3: 337-512 clouds with a size bound beyond 131,072 points (the workspace then has room for parked state, see
+        //    PCP_FPS_SLICE_TOP_B4): the per-shape launches are two resident workgroups per CU for whole and halved buckets and a
+        //    sliced launch for quartered ones; a mixed batch goes as one any-shape SLICED launch instead (400 tabletop frames:
+        //    4.65 ms shape after shape)
+        else if (!c.ctl_only && c.slice == 0 && c.mp == 0 && c.B > PCP_FPS_SLICE_TOP_B && c.B > fps_cu_count() &&
+                 max_pts > 2 * W && fps_slice_wanted(c.B, c.K, 0, 4 * W)) c.any_shape = 3;
     }
     if (c.slice_ctl) {           // every waiting slot of the three sliced shapes: "extra cloud, not started"; clouds per shape
         hipLaunchKernelGGL(fps_slice_prep, dim3(1), dim3(256), 0, c.st, c.offsets, c.B, c.total_pts, c.m_cap, c.slice_ctl);

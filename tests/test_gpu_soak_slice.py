@@ -116,13 +116,18 @@ def test_fps_mixed_size_episode_goes_as_one_any_shape_sliced_launch():
     sample; a batch of one shape only still goes through its own per-shape launch (same check)."""
     import stress_fps
     rng = np.random.default_rng(300)
-    for case, (B, K, dm) in enumerate(((300, 300, 1), (272, 257, 0), (300, 256, 1))):
+    for case, (B, K, dm) in enumerate(((300, 300, 1), (272, 257, 0), (300, 256, 1), (400, 256, 1))):
         if case == 0:
             sizes = rng.integers(60000, 72000, B)                  # whole and halved buckets, about half each
             sizes[7], sizes[150], sizes[299] = 0, 140000, 65536
         elif case == 1:
             sizes = rng.integers(20000, 30000, B)
             sizes[5], sizes[100], sizes[271] = 70000, 135000, 65537   # three shapes, two of them with one cloud only
+        elif case == 3:
+            # 337-512 clouds with a size bound beyond 131,072 points: the per-shape launches are resident (two workgroups per CU)
+            # for whole / halved buckets and sliced for quartered ones; the mixed batch goes as one any-shape sliced launch
+            sizes = rng.integers(30000, 70000, B)
+            sizes[3], sizes[399] = 135000, 0
         else:
             sizes = rng.integers(66000, 70000, B)                  # one shape (halved buckets) only
         base = stress_fps.make_cloud(rng, int(sizes.max()))
@@ -139,7 +144,7 @@ def test_fps_mixed_size_episode_goes_as_one_any_shape_sliced_launch():
             torch.cuda.synchronize()
             assert int(got.overflow.item()) == 0
             assert torch.equal(gi, ri) and torch.equal(gx.view(torch.int32), rx.view(torch.int32)), (case, rep)
-        for b in (0, 5, 7, 100, 150, B - 1):
+        for b in (0, 3, 5, 7, 100, 150, B - 1):
             if sizes[b] == 0:
                 assert (gi[b] == -1).all()
                 continue

@@ -30,6 +30,8 @@ def main(argv=None):
             B = int(rng.integers(513, 625))                             # two launches over the halves of the batch
         # tops beyond 65,536 make mixed-size batches: those go as ONE any-shape sliced launch
         top = int(rng.choice([6000, 30000, 65536, 100000, 150000])) if not auto else int(rng.choice([8000, 30000, 65536, 90000, 140000]))
+        if auto and top > 131072 and rng.random() < 0.5:
+            B = int(rng.integers(337, 513))                             # mixed batch of 337-512 clouds: one any-shape sliced launch
         sizes = rng.integers(2048, top + 1, B)
         sizes[rng.integers(0, B)] = top
         if rng.random() < 0.3:
